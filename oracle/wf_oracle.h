@@ -1,0 +1,108 @@
+/*
+ * wf_oracle.h - CPU parity oracle for the batched wildfire CA step.
+ *
+ * TEST INFRASTRUCTURE ONLY.  May be imported / linked / executed only by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, and there only
+ * as the checker.  The product path (wildfire_control_python_amd/) never touches it.
+ *
+ * Parity status: PINNED.  The oracle is checked against golden vectors produced by
+ * running the real reference in the build container (tests/golden/gen_golden.py,
+ * fixtures tests/golden/ref_*.npz; test: tests/test_oracle_golden.py).
+ *
+ * It is a plain-C restatement of the reference's algorithm that keeps the
+ * reference's own arithmetic: float64 temperature accumulation, a burning-cell
+ * list walked from a snapshot, per-neighbour heat application with the
+ * "temp > threshold" test after every single addition.  It is deliberately NOT
+ * the synchronous integer rule the HIP kernels implement, so that agreement
+ * between the two is evidence and not a tautology.
+ *
+ * State exchange format = the build's boundary format:
+ *   planes : int8 (batch, H, W, 4), C-contiguous, H <-> y, W <-> x,
+ *            plane 0 type (0 grass,1 fire,2 burnt,3 dirt,4 water; utility.py:128-140)
+ *            plane 1 fuel (utility.py:99)      plane 2 heat quantum count
+ *            plane 3 agent_pos (utility.py:121)
+ *            heat count q <-> reference temp: temp = q equal float64 addends of
+ *            wind_speed*heat (environment.py:286-290); q == WFO_HEAT_FORCED <->
+ *            temp = threshold+1 written by set_fire_to() on a cold cell (:236-237).
+ *   envs   : one wfo_env per environment (agent + world scalars).
+ */
+#ifndef WF_ORACLE_H
+#define WF_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { WFO_P_TYPE = 0, WFO_P_FUEL = 1, WFO_P_HEAT = 2, WFO_P_AGENT = 3 };
+enum { WFO_GRASS = 0, WFO_FIRE = 1, WFO_BURNT = 2, WFO_DIRT = 3, WFO_WATER = 4 };
+
+enum {
+    WFO_F_ALIVE     = 1,   /* World.agents non-empty (environment.py:206-208)            */
+    WFO_F_VISIBLE   = 2,   /* agent_pos plane holds the agent (cleared by a rejected move, :142) */
+    WFO_F_DIGGING   = 4,   /* Agent.digging (:112)                                        */
+    WFO_F_DEAD      = 8,   /* Agent.dead set by move() (:154-155), consumed by update()   */
+    WFO_F_RUNNING   = 16,  /* World.RUNNING (:196, forest_fire.py:105-106)                */
+    WFO_F_BORDER    = 32,  /* World.fire_at_border (:245-246)                             */
+    WFO_F_CONTAINED = 64   /* border_points deque exhausted: containment paid (:361-367)  */
+};
+
+typedef struct {
+    uint16_t x, y;       /* agent position (valid while ALIVE)            */
+    uint16_t flags;      /* WFO_F_*                                        */
+    uint16_t reserved;
+    uint32_t episode;    /* number of resets this env has seen             */
+    uint32_t tick;       /* update() calls since the last reset            */
+} wfo_env;
+
+typedef struct {
+    double wind_speed;       /* constants.py:39   0.54            */
+    double wind_x, wind_y;   /* constants.py:39   (0,0)           */
+    double heat;             /* utility.py:98     0.3             */
+    double threshold;        /* utility.py:100    3               */
+    double death_penalty;    /* constants.py:32  -1000            */
+    double contained_bonus;  /* constants.py:33   1000            */
+    double default_reward;   /* constants.py:34  -1               */
+    int32_t allow_dig_toggle;/* constants.py:46   0               */
+    int32_t containment;     /* 1 = evaluate the A*-based "contained" test of get_reward */
+    /* synthetic reset law (build extension; reference default = lo==hi==20, ppm 0) */
+    int32_t fuel_lo, fuel_hi;
+    uint32_t ignite_ppm;     /* extra pre-ignited grass cells per million  */
+    int32_t reserved;
+} wfo_params;
+
+#define WFO_HEAT_FORCED 25
+
+void wfo_default_params(wfo_params *p);
+
+/* One ForestFire.step() per environment, in place (forest_fire.py:30-49).
+ * actions: int8[batch] (0..3 = N,S,E,W; 4 = dig toggle when allowed; else no-op),
+ *          NULL = all no-op.  do_update: whether update() runs this step
+ *          (the a_speed counter of forest_fire.py:40-43 is kept by the caller).
+ * Environments that are not RUNNING are left untouched: reward 0, done 1.
+ * Returns 0, or -1 on bad arguments. */
+int wfo_step(int batch, int H, int W, int8_t *planes, wfo_env *envs,
+             const int8_t *actions, int do_update, const wfo_params *p,
+             double *reward, uint8_t *done);
+
+/* World.reset() per environment where mask[i] != 0 (mask NULL = all), with the
+ * build's counter-based stream keyed by (seed, env_id0 + i, episode) replacing
+ * numpy's legacy RNG (environment.py:186-212, utility.py:66-78). */
+int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
+              const uint8_t *mask, uint64_t seed, uint64_t env_id0,
+              const wfo_params *p);
+
+/* World.get_state() (environment.py:399-402): int8 (batch, W, H, 3) indexed [b][x][y][k]. */
+int wfo_get_state(int batch, int H, int W, const int8_t *planes, int8_t *obs);
+
+/* The counter-based stream itself (for tests of the generator). */
+uint32_t wfo_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t draw);
+
+/* Agent spawn table: circle_points() of utility.py:8-52 around (0,0); returns the
+ * number of points written to dx/dy (capacity >= 32). */
+int wfo_circle_points(int r, int *dx, int *dy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: drives the REAL reference implementation.
+
+Runs only in the build container (it needs /root/reference, which never travels
+to the GPU box).  It imports the reference's ``Simulation`` package unchanged,
+read-only, from where it lies, drives ``ForestFire.step()/reset()`` with scripted
+action sequences / poked fuel planes, and dumps small ``.npz`` fixtures next to
+this file.  The fixtures are DATA (inputs + the reference's outputs); no
+reference source text is stored.
+
+Two third-party pieces of the reference's environment are absent in this image
+ and are provided here, in this script only:
+
+* PyPI ``colour`` (reference Simulation/utility.py:1): a stand-in exposing
+  ``Color(name).red/.green/.blue`` for the five web colours the reference uses.
+  It only feeds the cosmetic ``gray`` layer, never an integer plane recorded below.
+* ``pyastar.astar_path``: the reference's wrapper (pyastar/pyastar.py:7-22)
+  loads ``astar.so`` from its own (read-only) directory, so a loader with the
+  same call contract is registered that binds the reference's own native code,
+  compiled by ``oracle/Makefile`` from /root/reference/pyastar/astar.cpp into
+  ``oracle/_ref/astar.so``.
+
+Usage:  python tests/golden/gen_golden.py            (both sizes, subprocesses)
+        python tests/golden/gen_golden.py --size 10  (one size, in-process)
+
+Reference facts relied on (file:line under /root/reference):
+  Simulation/environment.py:22-23   WIDTH/HEIGHT frozen at import -> one process per size
+  Simulation/environment.py:38-50   env is float64 (W,H,9) indexed [x,y,layer]
+  Simulation/forest_fire.py:30-49   step() -> [state, reward, done, {}]
+"""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+ASTAR_SO = os.path.join(REPO, "oracle", "_ref", "astar.so")
+
+# plane order of the build's int8 (batch,H,W,4) state buffer
+P_TYPE, P_FUEL, P_HEAT, P_AGENT = 0, 1, 2, 3
+HEAT_FORCED = 25  # round((threshold+1)/0.162): set_fire_to() on a cold cell, environment.py:236-237
+
+
+def _install_stand_ins():
+    sys.dont_write_bytecode = True
+    # --- colour -----------------------------------------------------------
+    rgb = {"green": (0.0, 128 / 255.0, 0.0), "red": (1.0, 0.0, 0.0),
+           "black": (0.0, 0.0, 0.0), "brown": (165 / 255.0, 42 / 255.0, 42 / 255.0),
+           "blue": (0.0, 0.0, 1.0)}
+
+    class Color:
+        def __init__(self, name):
+            self.red, self.green, self.blue = rgb[name.lower()]
+
+    m = types.ModuleType("colour")
+    m.Color = Color
+    sys.modules["colour"] = m
+
+    # --- pyastar (binds the reference's own compiled astar.cpp) -------------
+    lib = ctypes.cdll.LoadLibrary(ASTAR_SO)
+    f32 = np.ctypeslib.ndpointer(dtype=np.float32, ndim=1, flags="C_CONTIGUOUS")
+    i32 = np.ctypeslib.ndpointer(dtype=np.int32, ndim=1, flags="C_CONTIGUOUS")
+    lib.astar.restype = ctypes.c_bool
+    lib.astar.argtypes = [f32, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                          ctypes.c_int, ctypes.c_bool, i32]
+
+    def astar_path(weights, start, goal, allow_diagonal=False):
+        # contract of reference pyastar/pyastar.py:25-64: empty array <=> no path
+        h, w = weights.shape
+        s = int(start[0]) * w + int(start[1])
+        g = int(goal[0]) * w + int(goal[1])
+        paths = np.full(h * w, -1, dtype=np.int32)
+        ok = lib.astar(np.ascontiguousarray(weights, dtype=np.float32).ravel(),
+                       h, w, s, g, bool(allow_diagonal), paths)
+        if not ok or s == g:
+            return np.array([])
+        out, p = [], g
+        while p != s:
+            out.append(divmod(p, w))
+            p = int(paths[p])
+        out.append(divmod(s, w))
+        return np.array(out[::-1])
+
+    pkg = types.ModuleType("pyastar")
+    pkg.__path__ = []
+    sub = types.ModuleType("pyastar.pyastar")
+    sub.astar_path = astar_path
+    pkg.pyastar = sub
+    sys.modules["pyastar"] = pkg
+    sys.modules["pyastar.pyastar"] = sub
+
+
+class Recorder:
+    """Collects one fixture file worth of episodes."""
+
+    def __init__(self, sim, layer, size):
+        self.sim, self.layer, self.size = sim, layer, size
+        self.c = 0.54 * 0.3 * (0 + 1) ** (-1)  # environment.py:286-287 with wind (0,0)
+        self.rows = {k: [] for k in ("planes", "agent", "reward", "done", "obs",
+                                     "fab", "border_len", "action")}
+        self.init_planes, self.init_agent, self.init_world, self.ep_start = [], [], [], []
+
+    def _seqsum(self, n):
+        t = 0.0
+        for _ in range(int(n)):
+            t += self.c
+        return t
+
+    def _planes(self):
+        W = self.sim.W
+        env, L = W.env, self.layer
+        temp = env[:, :, L["temp"]]
+        q = np.rint(temp / self.c).astype(np.int64)
+        # the float64 temperature must be exactly the running sum of q equal addends
+        # (order independence claim of SURVEY 8a) or the forced value threshold+1
+        for (x, y), v in np.ndenumerate(q):
+            t = temp[x, y]
+            if v == HEAT_FORCED and t == 4.0:
+                continue
+            assert t == self._seqsum(v), (x, y, t, v)
+        p = np.zeros((self.size, self.size, 4), dtype=np.int8)  # [y, x, plane]
+        p[:, :, P_TYPE] = env[:, :, L["type"]].T
+        p[:, :, P_FUEL] = env[:, :, L["fuel"]].T
+        p[:, :, P_HEAT] = q.T
+        p[:, :, P_AGENT] = env[:, :, L["agent_pos"]].T
+        # derived layers are pure functions of type (environment.py:85,133)
+        fm = env[:, :, L["fire_mobility"]]
+        assert np.array_equal(np.isinf(fm), env[:, :, L["type"]] >= 3)
+        return p
+
+    def _agent(self):
+        W = self.sim.W
+        if W.agents:
+            a = W.agents[0]
+            return [int(a.x), int(a.y), 1, int(a.digging), int(a.dead)]
+        return [-1, -1, 0, 0, 1]
+
+    def begin(self):
+        self.ep_start.append(len(self.rows["action"]))
+        self.init_planes.append(self._planes())
+        self.init_agent.append(self._agent())
+        self.init_world.append([int(self.sim.W.fire_at_border), len(self.sim.W.border_points)])
+
+    def step(self, action):
+        state, reward, done, _ = self.sim.step(action)
+        r = self.rows
+        r["planes"].append(self._planes())
+        r["agent"].append(self._agent())
+        r["reward"].append(float(reward))
+        r["done"].append(bool(done))
+        r["obs"].append(np.asarray(state).astype(np.int8))  # [x, y, k] as the reference returns it
+        r["fab"].append(bool(self.sim.W.fire_at_border))
+        r["border_len"].append(len(self.sim.W.border_points))
+        r["action"].append(int(action))
+        return state, reward, done
+
+    def save(self, path):
+        r = self.rows
+        np.savez_compressed(
+            path,
+            size=np.int32(self.size),
+            ep_start=np.asarray(self.ep_start + [len(r["action"])], dtype=np.int64),
+            init_planes=np.asarray(self.init_planes, dtype=np.int8),
+            init_agent=np.asarray(self.init_agent, dtype=np.int16),
+            init_world=np.asarray(self.init_world, dtype=np.int32),   # [fire_at_border, len(border_points)]
+            action=np.asarray(r["action"], dtype=np.int8),
+            planes=np.asarray(r["planes"], dtype=np.int8),
+            agent=np.asarray(r["agent"], dtype=np.int16),
+            reward=np.asarray(r["reward"], dtype=np.float64),
+            done=np.asarray(r["done"], dtype=np.uint8),
+            obs=np.asarray(r["obs"], dtype=np.int8),
+            fire_at_border=np.asarray(r["fab"], dtype=np.uint8),
+            border_len=np.asarray(r["border_len"], dtype=np.int32),
+        )
+        print(f"  wrote {os.path.relpath(path, REPO)}: {len(self.ep_start)} episodes, "
+              f"{len(r['action'])} steps, {os.path.getsize(path)} bytes")
+
+
+def circling_policy(sim, rng, avoid_fire=True):
+    """Own scripted policy (not the reference's): walk clockwise around the fire,
+    refusing moves into a burning cell when another is available."""
+    W = sim.W
+    if not W.agents:
+        return 0
+    a = W.agents[0]
+    mx, my = W.WIDTH // 2, W.HEIGHT // 2
+    if a.x >= mx and a.y > my:
+        opts = [1, 3]
+    elif a.x > mx and a.y <= my:
+        opts = [1, 2]
+    elif a.x <= mx and a.y < my:
+        opts = [0, 2]
+    else:
+        opts = [0, 3]
+    for _ in range(8):
+        act = int(opts[rng.integers(len(opts))])
+        if not avoid_fire or not a.fire_in_direction(act):
+            return act
+    return act
+
+
+def run_size(size):
+    _install_stand_ins()
+    sys.path.insert(0, REF)
+    from Simulation import constants
+    constants.METADATA["width"] = size
+    constants.METADATA["height"] = size
+    from Simulation.forest_fire import ForestFire  # noqa: E402  (reference, unchanged)
+    from Simulation.utility import layer
+    import random
+
+    sim = ForestFire()
+    assert sim.W.WIDTH == size and sim.W.HEIGHT == size
+    out = lambda name: os.path.join(HERE, f"ref_{size}_{name}.npz")
+    NOOP = 5
+
+    def reset(seed):
+        np.random.seed(seed)
+        random.seed(seed)
+        sim.reset()
+
+    # 1. known-answer episode of SURVEY 8a: seed 0, no-op actions until done
+    rec = Recorder(sim, layer, size)
+    reset(0)
+    rec.begin()
+    done = False
+    while not done:
+        _, _, done = rec.step(NOOP)
+    rec.save(out("noop"))
+
+    # 2. uniformly random actions 0..3 with ~10% no-ops (digs, rejected moves, deaths)
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(1000 + size)
+    for ep in range(24):
+        reset(100 + ep)
+        rec.begin()
+        done = False
+        while not done:
+            a = int(rng.integers(0, 4)) if rng.random() > 0.1 else NOOP
+            _, _, done = rec.step(a)
+    rec.save(out("random"))
+
+    # 3. circling policy: digs a ring -> exercises the containment (+1000) reward
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(2000 + size)
+    for ep in range(16):
+        reset(200 + ep)
+        rec.begin()
+        done = False
+        while not done:
+            _, _, done = rec.step(circling_policy(sim, rng, avoid_fire=(ep % 4 != 3)))
+    rec.save(out("circle"))
+
+    # 4. random fuel U{10..40} poked after reset (BASELINE configs 2-5), random + no-op actions
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(3000 + size)
+    for ep in range(12):
+        reset(300 + ep)
+        sim.W.env[:, :, layer["fuel"]] = rng.integers(10, 41, size=(size, size)).astype(np.float64)
+        rec.begin()
+        done = False
+        while not done:
+            if ep % 3 == 0:
+                a = NOOP
+            elif ep % 3 == 1:
+                a = int(rng.integers(0, 4))
+            else:
+                a = circling_policy(sim, rng)
+            _, _, done = rec.step(a)
+    rec.save(out("randfuel"))
+
+    # 5. several ignition points + low fuel (fronts merge, burn-outs next to ignitions)
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(4000 + size)
+    for ep in range(8):
+        reset(400 + ep)
+        sim.W.env[:, :, layer["fuel"]] = rng.integers(6, 31, size=(size, size)).astype(np.float64)
+        for _ in range(3):
+            x, y = int(rng.integers(0, size)), int(rng.integers(0, size))
+            if sim.W.is_burnable((x, y)):
+                sim.W.set_fire_to((x, y))
+        rec.begin()
+        done = False
+        while not done:
+            a = int(rng.integers(0, 4)) if ep % 2 else NOOP
+            _, _, done = rec.step(a)
+    rec.save(out("multifire"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=0)
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("reference not present: fixtures can only be regenerated in the build container")
+    if not os.path.exists(ASTAR_SO):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "ref"])
+    if args.size:
+        run_size(args.size)
+        return
+    for size in (10, 14):
+        print(f"size {size}:")
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--size", str(size)])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""Helpers shared by the parity tests: load the reference-generated fixtures
+(tests/golden/ref_*.npz, produced by tests/golden/gen_golden.py from the real
+reference) and lay their episodes out as a batch of environments."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixture_files(size=None):
+    pat = f"ref_{size}_*.npz" if size else "ref_*.npz"
+    return sorted(glob.glob(os.path.join(GOLDEN, pat)))
+
+
+class Episodes:
+    """All episodes of one fixture file as a batch: env b = episode b."""
+
+    def __init__(self, path):
+        d = np.load(path)
+        self.name = os.path.basename(path)
+        self.size = int(d["size"])
+        self.ep_start = d["ep_start"]
+        self.B = len(self.ep_start) - 1
+        self.lengths = np.diff(self.ep_start)
+        self.T = int(self.lengths.max())
+        self.d = d
+        self.init_planes = np.ascontiguousarray(d["init_planes"])
+        ia = d["init_agent"]
+        e = np.zeros(self.B, dtype=O.ENV_DTYPE)
+        e["x"], e["y"] = ia[:, 0], ia[:, 1]
+        iw = d["init_world"]
+        e["flags"] = (O.F_ALIVE | O.F_VISIBLE | O.F_DIGGING | O.F_RUNNING) \
+            | (iw[:, 0] != 0) * O.F_BORDER | (iw[:, 1] == 0) * O.F_CONTAINED
+        self.init_envs = e
+
+    def actions_at(self, t):
+        """int8 (B,) actions of step t (no-op 5 where the episode is over)."""
+        a = np.full(self.B, 5, dtype=np.int8)
+        live = self.lengths > t
+        a[live] = self.d["action"][self.ep_start[:-1][live] + t]
+        return a, live
+
+    def expected_at(self, t, key):
+        live = self.lengths > t
+        return self.d[key][self.ep_start[:-1][live] + t], live
+
+    def check_step(self, t, planes, envs, reward, done, obs=None, what="oracle"):
+        """Compare one batched step against the reference rows; returns live mask."""
+        tag = f"{self.name} step {t} ({what})"
+        exp_planes, live = self.expected_at(t, "planes")
+        np.testing.assert_array_equal(planes[live], exp_planes, err_msg=tag + " planes")
+        agent, _ = self.expected_at(t, "agent")
+        alive = (envs["flags"][live] & O.F_ALIVE) != 0
+        np.testing.assert_array_equal(alive, agent[:, 2] != 0, err_msg=tag + " alive")
+        np.testing.assert_array_equal(envs["x"][live][alive], agent[alive, 0], err_msg=tag + " x")
+        np.testing.assert_array_equal(envs["y"][live][alive], agent[alive, 1], err_msg=tag + " y")
+        exp_r, _ = self.expected_at(t, "reward")
+        np.testing.assert_array_equal(reward[live], exp_r, err_msg=tag + " reward")
+        exp_d, _ = self.expected_at(t, "done")
+        np.testing.assert_array_equal(done[live], exp_d, err_msg=tag + " done")
+        fab, _ = self.expected_at(t, "fire_at_border")
+        np.testing.assert_array_equal((envs["flags"][live] & O.F_BORDER) != 0, fab != 0,
+                                      err_msg=tag + " fire_at_border")
+        bl, _ = self.expected_at(t, "border_len")
+        np.testing.assert_array_equal((envs["flags"][live] & O.F_CONTAINED) != 0, bl == 0,
+                                      err_msg=tag + " contained")
+        if obs is not None:
+            exp_o, _ = self.expected_at(t, "obs")
+            np.testing.assert_array_equal(obs[live], exp_o, err_msg=tag + " obs")
+        return live
