@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the batched wildfire CA step on MI355X.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): 65 536 batched
+14x14 grids per GPU, random fuel U{10..40}, agent dig-actions (uniform N/S/E/W)
+injected every step, containment test on, finished environments auto-reset on
+the device so every environment does real work in every timed step.
+A "step" = ONE wf_step_device launch = one ForestFire.step() for every env
+(one CA tick per launch: the honest HBM-bound shape; the fused multi-tick rate is
+reported separately as `fused`).  State and actions are resident in HBM before the
+timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: environments are independent -> the global batch is sharded
+contiguously, one process per GPU, NO collective on the data path (weak scaling:
+65 536 envs per GPU).  torch.distributed is used only for the timing barrier and
+the max-over-ranks reduction.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL_UPDATE = 8      # 4 int8 planes read + 4 written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
+    ap.add_argument("--size", type=int, default=14)
+    ap.add_argument("--fused", type=int, default=16, help="steps per launch of the extra fused measurement (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def make_actions(steps, lo, hi, seed):
+    """(steps, hi-lo) int8 uniform N/S/E/W; column i belongs to GLOBAL env lo+i, so the
+    action stream of an environment does not depend on how the batch is sharded."""
+    out = np.empty((steps, hi - lo), dtype=np.int8)
+    blk = 8192
+    for g0 in range((lo // blk) * blk, hi, blk):
+        r = np.random.default_rng([seed, g0 // blk]).integers(0, 4, size=(steps, blk), dtype=np.int8)
+        a, b = max(g0, lo), min(g0 + blk, hi)
+        out[:, a - lo:b - lo] = r[:, a - g0:b - g0]
+    return out
+
+
+def cpu_baseline(size, seed, seconds):
+    """The oracle (plain-C restatement of the reference step, 1 thread) on a bounded
+    sample of the same workload: 2048 envs, same fuel law / action law / auto-reset."""
+    from oracle import oracle as O
+    B = 2048
+    p = O.default_params(fuel_lo=10, fuel_hi=40)
+    planes, envs = O.new_state(B, size, size)
+    O.reset(planes, envs, seed=seed, params=p)
+    rng = np.random.default_rng(seed)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        a = rng.integers(0, 4, size=B).astype(np.int8)
+        _, done = O.step(planes, envs, a, p)
+        if done.any():
+            O.reset(planes, envs, seed=seed, mask=done, params=p)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": B * size * size * steps / el, "unit": "cell-updates/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{B} envs x {size}x{size}, {steps} steps in {el:.1f}s, oracle/wf_oracle.c single thread "
+                      f"(reference Python path: 5.5e5 cell-updates/s on 1 core, BASELINE.md section 2)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    n_gpus = world
+
+    from wildfire_control_python_amd import make_shard
+    S, B, K, Wm = args.size, args.batch, args.steps, args.warmup
+    cells = B * S * S
+    env = make_shard(B * world, S, rank=rank, world_size=world, device=local, seed=args.seed,
+                     auto_reset=True, fuel_range=(10, 40), containment=True)
+    lo = rank * B
+    env.reset(seed=args.seed)
+    total = Wm + K
+    dev = torch.device("cuda", local)
+    d_act = torch.from_numpy(make_actions(total, lo, lo + B, args.seed)).to(dev)
+    d_rew = torch.empty((1, B), dtype=torch.float64, device=dev)
+    d_done = torch.empty((1, B), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(Wm):
+        env.step_device(d_act[s], 1, d_rew, d_done, update_mask=1)
+    env.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    env.timer_start()
+    for s in range(Wm, total):
+        env.step_device(d_act[s], 1, d_rew, d_done, update_mask=1)
+    ev_ms = env.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    done_frac = float(d_done.float().mean().item())
+
+    # extra: fused steps per launch (grid stays in registers between ticks)
+    fused = None
+    if args.fused > 1:
+        F = args.fused
+        reps = max(1, K // F)
+        d_act_f = torch.from_numpy(make_actions(F, lo, lo + B, args.seed + 1)).to(dev)
+        d_rew_f = torch.empty((F, B), dtype=torch.float64, device=dev)
+        d_done_f = torch.empty((F, B), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        env.step_device(d_act_f, F, d_rew_f, d_done_f, update_mask=(1 << F) - 1)
+        env.sync()
+        env.timer_start()
+        for _ in range(reps):
+            env.step_device(d_act_f, F, d_rew_f, d_done_f, update_mask=(1 << F) - 1)
+        f_ms = env.timer_stop()
+        fused = {"steps_per_launch": F, "launches": reps,
+                 "cell_updates_per_s_per_gpu": cells * F * reps / (f_ms * 1e-3)}
+
+    t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, ev_max = float(t[0].item()), float(t[1].item())
+
+    if rank == 0:
+        value = cells * world * K / wall_max
+        launch_ms = ev_max / K
+        achieved = BYTES_PER_CELL_UPDATE * cells / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "cell-updates/sec",
+            "value": value,
+            "unit": "cell-updates/s",
+            "n_gpus": n_gpus,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": wall_max / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{B} batched {S}x{S} grids per GPU, random fuel U{{10..40}}, "
+                                   "uniform N/S/E/W dig-action injected each step, containment test on, "
+                                   "device auto-reset of finished envs (BASELINE configs[2])",
+                       "global_batch": B * world, "grid": [S, S], "ticks_per_launch": 1,
+                       "parallelism": f"env-shard x{world}, no collective",
+                       "kernel": env.kernel_name},
+            "env_steps_per_s": value / (S * S),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "wf_step_wave", "launch_us": launch_ms * 1e3,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells},
+            "done_frac_last_step": done_frac,
+        }
+        if fused:
+            out["fused"] = fused
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, args.seed, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

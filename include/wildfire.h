@@ -1,0 +1,160 @@
+/*
+ * wildfire.h - C-ABI of the MI355X-native batched wildfire cellular-automaton step.
+ *
+ * Drop-in boundary for ONE hot path of dashdeckers/Wildfire-Control-Python: the
+ * per-cell fire-spread update and the step()/reset()/get_state() surface around it
+ *     Simulation/forest_fire.py:30-49   ForestFire.step
+ *     Simulation/forest_fire.py:52-54   ForestFire.reset
+ *     Simulation/forest_fire.py:85-106  ForestFire.update (the CA tick)
+ *     Simulation/environment.py:99-171  Agent.move / dig / is_dead
+ *     Simulation/environment.py:186-402 World.reset / set_fire_to / reduce_fuel /
+ *                                       apply_heat_from_to / get_reward / get_state
+ *
+ * FFI convention = the reference's only existing FFI (pyastar/pyastar.py:7-22 binding
+ * pyastar/astar.cpp:41-47): a ctypes-loaded shared library, extern "C", plain
+ * pointers and sizes, caller-owned host buffers (C-contiguous numpy arrays), no
+ * exceptions across the boundary.  Differences, all forced by the device:
+ * state lives in HBM inside an opaque context (one context per GPU; a context is
+ * not thread-safe, distinct contexts are independent), every entry point returns
+ * 0 or a negative wf_status (never exit()/abort()), and each host-buffer entry
+ * point has a *_device twin that takes device pointers and is asynchronous on the
+ * context's HIP stream (for learners that keep tensors on the GPU).
+ *
+ * Boundary data formats
+ *   planes  int8 (batch, H, W, 4) C-contiguous; H <-> y, W <-> x (the reference
+ *           indexes env[x, y, layer], environment.py:38-50; the transpose happens
+ *           only in wf_get_state).  One 32-bit word per cell:
+ *             plane 0 type   0 grass 1 fire 2 burnt 3 dirt 4 water (utility.py:128-140)
+ *             plane 1 fuel   (utility.py:99; reduce_fuel environment.py:297-307)
+ *             plane 2 heat   number of heat quanta received = temp / (wind_speed*heat)
+ *                            (environment.py:286-290); WF_HEAT_FORCED marks
+ *                            temp = threshold+1 written by set_fire_to (:236-237)
+ *             plane 3 agent  agent_pos layer (utility.py:121)
+ *   envs    wf_env[batch]: agent and world scalars (Agent.x/.y/.dead/.digging,
+ *           World.RUNNING/.fire_at_border, "border deque exhausted")
+ *   actions int8: 0..3 = N,S,E,W (environment.py:163-171); 4 = dig toggle when
+ *           allow_dig_toggle (forest_fire.py:35-36); anything else = no-op
+ *   reward  float64 (exactly the Python float get_reward returns, environment.py:342-390)
+ *   done    uint8 = not World.RUNNING (forest_fire.py:48)
+ *   obs     int8 (batch, W, H, 3) indexed [b][x][y][k] = World.get_state()
+ *           (environment.py:399-402): agent_pos, type==fire, fire_mobility!=inf
+ */
+#ifndef WILDFIRE_H
+#define WILDFIRE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_ABI_VERSION 1
+
+enum { WF_P_TYPE = 0, WF_P_FUEL = 1, WF_P_HEAT = 2, WF_P_AGENT = 3 };
+enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4 };
+#define WF_HEAT_FORCED 25
+
+/* wf_env.flags */
+enum {
+    WF_F_ALIVE       = 1,    /* World.agents non-empty                  environment.py:206-208 */
+    WF_F_VISIBLE     = 2,    /* agent_pos plane shows the agent (a rejected move blanks it, :142) */
+    WF_F_DIGGING     = 4,    /* Agent.digging                           environment.py:112     */
+    WF_F_DEAD        = 8,    /* Agent.dead set by move(), consumed by update()  :154-155, :116-120 */
+    WF_F_RUNNING     = 16,   /* World.RUNNING                           forest_fire.py:105-106 */
+    WF_F_BORDER      = 32,   /* World.fire_at_border                    environment.py:245-246 */
+    WF_F_CONTAINED   = 64,   /* containment bonus already paid (border deque empty, :361-367)  */
+    WF_F_REACH_VALID = 128   /* internal: the context's border-reachability bitboard is current */
+};
+
+typedef struct wf_env {
+    uint16_t x, y;       /* agent position                                   */
+    uint16_t flags;      /* WF_F_*                                           */
+    uint16_t reserved;
+    uint32_t episode;    /* resets seen by this environment (keys the stream) */
+    uint32_t tick;       /* update() calls since the last reset               */
+} wf_env;
+
+typedef struct wf_params {
+    /* rule (integer restatement of environment.py:278-294, valid for wind vector (0,0)):
+     * a grass cell ignites when it has received >= ignite_count heat quanta */
+    int32_t ignite_count;      /* 19 for wind 0.54, heat 0.3, threshold 3 (constants.py:39, utility.py:98-100) */
+    int32_t allow_dig_toggle;  /* constants.py:46 */
+    int32_t containment;       /* 1: evaluate the "fire contained" test of get_reward (environment.py:345-377) */
+    int32_t auto_reset;        /* 1: a step on a finished env resets it instead (reward 0, done 0) */
+    double  death_penalty;     /* constants.py:32 */
+    double  contained_bonus;   /* constants.py:33 */
+    double  default_reward;    /* constants.py:34 */
+    /* synthetic reset law for wf_reset / auto_reset (reference default: 20, 20, 0) */
+    int32_t  fuel_lo, fuel_hi; /* fuel ~ U{lo..hi} per cell                            */
+    uint32_t ignite_ppm;       /* extra pre-ignited grass cells per million             */
+    int32_t  reserved;
+    uint64_t seed;             /* stream seed for auto_reset                            */
+    uint64_t env_id0;          /* global id of env 0 of this context (multi-GPU shards) */
+} wf_params;
+
+typedef enum wf_status {
+    WF_OK = 0,
+    WF_ERR_ARG = -1,          /* NULL / out-of-range argument                          */
+    WF_ERR_UNSUPPORTED = -2,  /* grid shape or option not supported by this build      */
+    WF_ERR_NO_DEVICE = -3,    /* no usable HIP device                                  */
+    WF_ERR_HIP = -4,          /* a HIP call failed; wf_last_hip_error() has the code   */
+    WF_ERR_NOMEM = -5
+} wf_status;
+
+typedef struct wf_ctx wf_ctx;
+
+int  wf_abi_version(void);
+void wf_default_params(wf_params *p);
+const char *wf_strerror(int status);
+int  wf_last_hip_error(const wf_ctx *ctx);
+
+/* Context: device state for `batch` environments of H x W cells on HIP device `device`.
+ * replaces: World.__init__ / create_map (environment.py:38-50, 175-183) */
+int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params *p);
+int wf_destroy(wf_ctx *ctx);
+int wf_set_params(wf_ctx *ctx, const wf_params *p);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int wf_set_stream(wf_ctx *ctx, void *hip_stream);
+
+/* Host <-> device state exchange (synchronous).  Either pointer may be NULL to skip it.
+ * replaces: direct numpy access to World.env (environment.py:38-50) */
+int wf_upload(wf_ctx *ctx, const int8_t *planes, const wf_env *envs);
+int wf_download(wf_ctx *ctx, int8_t *planes, wf_env *envs);
+
+/* World.reset() (environment.py:186-212) for envs with mask[i] != 0 (NULL = all), spawn
+ * drawn from the counter-based stream keyed by (seed, env_id0 + i, episode). */
+int wf_reset(wf_ctx *ctx, const uint8_t *mask, uint64_t seed);
+int wf_reset_device(wf_ctx *ctx, const uint8_t *d_mask, uint64_t seed);
+
+/* n_steps x ForestFire.step() (forest_fire.py:30-49).
+ *   actions int8 (n_steps, batch), NULL = no-op;  reward float64 (n_steps, batch);
+ *   done uint8 (n_steps, batch); reward/done may be NULL.
+ * update() runs every params-independent a_speed-th step: the caller passes
+ * update_mask, bit s = run update() in step s (all ones for a_speed = 1; n_steps <= 64).
+ * wf_step is synchronous with host buffers; wf_step_device is asynchronous on the
+ * context's stream with device buffers. */
+int wf_step(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mask,
+            double *reward, uint8_t *done);
+int wf_step_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
+                   double *d_reward, uint8_t *d_done);
+
+/* World.get_state() (environment.py:399-402) for the whole batch. */
+int wf_get_state(wf_ctx *ctx, int8_t *obs);
+int wf_get_state_device(wf_ctx *ctx, int8_t *d_obs);
+
+int wf_sync(wf_ctx *ctx);
+
+/* Zero-copy access for device-side consumers; pointers stay valid until wf_destroy. */
+void *wf_planes_device(wf_ctx *ctx);   /* int8 (batch,H,W,4) current state */
+void *wf_envs_device(wf_ctx *ctx);     /* wf_env[batch]                     */
+
+/* HIP-event timing on the context's stream (bench.py's roofline leg). */
+int wf_timer_start(wf_ctx *ctx);
+int wf_timer_stop(wf_ctx *ctx, float *elapsed_ms);   /* synchronises */
+
+/* Introspection: name of the kernel family serving this context's grid shape. */
+const char *wf_kernel_name(const wf_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

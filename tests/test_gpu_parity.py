@@ -1,0 +1,306 @@
+"""GPU parity tests (run with `pytest -m gpu` on an MI355X).
+
+Everything goes through the C-ABI (libwildfire_hip.so via ctypes).  The HIP path is
+compared bit-exactly (integer planes, scalars, float64 rewards) with
+  * the reference's own outputs (tests/golden/ref_*.npz), and
+  * the CPU oracle on the same seeded inputs,
+and at BASELINE.json's full sizes through size-independent properties.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.golden_util import Episodes, fixture_files
+
+pytestmark = pytest.mark.gpu
+
+VIS = np.uint16(~np.uint16(128))  # drop WF_F_REACH_VALID (internal cache flag) before comparing
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import wildfire_control_python_amd as pkg
+    from wildfire_control_python_amd import _native
+    _native.lib()   # fail loudly if the HIP library is missing
+    return pkg
+
+
+def _envs(ge):
+    e = ge.copy()
+    e["flags"] &= VIS
+    return e
+
+
+# --------------------------------------------------------------- reference fixtures
+@pytest.mark.parametrize("path", fixture_files(), ids=lambda p: p.split("/")[-1])
+def test_hip_reproduces_reference(wf, path):
+    ep = Episodes(path)
+    env = wf.BatchedForestFire(ep.B, size=ep.size)
+    env.upload(ep.init_planes, ep.init_envs)
+    n_contained = 0
+    for t in range(ep.T):
+        actions, _ = ep.actions_at(t)
+        obs, reward, done, _ = env.step(actions)
+        planes, envs = env.download()
+        live = ep.check_step(t, planes, envs, reward, done.astype(np.uint8), obs, what="hip")
+        n_contained += int((reward[live] == 1000.0).sum())
+    if "circle" in path:
+        assert n_contained > 0
+    env.close()
+
+
+# ------------------------------------------------------------------ HIP vs oracle
+SHAPES = [(14, 14), (10, 10), (8, 8), (12, 12), (16, 16), (16, 8), (8, 16), (20, 10), (10, 20)]
+
+
+@pytest.mark.parametrize("W,H", SHAPES)
+def test_step_matches_oracle_random_actions(wf, W, H):
+    B, T = 512, 160
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(6, 30), ignite_ppm=20000)
+    env.reset(seed=77)
+    op = O.default_params(fuel_lo=6, fuel_hi=30, ignite_ppm=20000)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=77, params=op)
+    gp, ge = env.download()
+    np.testing.assert_array_equal(gp, planes, err_msg="reset planes")
+    np.testing.assert_array_equal(_envs(ge), envs, err_msg="reset envs")
+    rng = np.random.default_rng(W * 100 + H)
+    n_done = 0
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)      # includes no-ops (4 is a no-op here, 5 too)
+        obs, r, d, _ = env.step(a)
+        ro, do = O.step(planes, envs, a, op)
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        n_done = int(do.sum())
+    assert n_done > B // 4, "episodes should finish within the horizon"
+    env.close()
+
+
+def test_fused_steps_equal_single_steps(wf):
+    B, T = 256, 48
+    a = np.random.default_rng(3).integers(0, 5, size=(T, B)).astype(np.int8)
+    e1 = wf.BatchedForestFire(B, size=14, fuel_range=(10, 40))
+    e2 = wf.BatchedForestFire(B, size=14, fuel_range=(10, 40))
+    e1.reset(seed=9)
+    e2.reset(seed=9)
+    r1 = np.stack([e1.step(a[t])[1] for t in range(T)])
+    r2a, d2a = e2.step_many(a[:16])
+    r2b, d2b = e2.step_many(a[16:])
+    np.testing.assert_array_equal(np.concatenate([r2a, r2b]), r1)
+    p1, s1 = e1.download()
+    p2, s2 = e2.download()
+    np.testing.assert_array_equal(p1, p2)
+    np.testing.assert_array_equal(_envs(s1), _envs(s2))
+    e1.close()
+    e2.close()
+
+
+def test_a_speed_two_updates_every_other_step(wf):
+    B = 128
+    env = wf.BatchedForestFire(B, size=10, metadata={"a_speed": 2, "a_speed_iter": 2})
+    env.reset(seed=4)
+    op = O.default_params()
+    planes, envs = O.new_state(B, 10, 10)
+    O.reset(planes, envs, seed=4, params=op)
+    rng = np.random.default_rng(8)
+    for t in range(60):
+        a = rng.integers(0, 4, size=B).astype(np.int8)
+        _, r, d, _ = env.step(a)
+        ro, do = O.step(planes, envs, a, op, do_update=(t % 2 == 1))   # forest_fire.py:40-43
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(r, ro)
+    env.close()
+
+
+def test_dig_toggle_matches_oracle_outside_documented_corner(wf):
+    """allow_dig_toggle (forest_fire.py:35-36).  The one documented divergence - toggling
+    digging ON while standing on a burning cell - is excluded from the comparison."""
+    B = 512
+    env = wf.BatchedForestFire(B, size=10, metadata={"allow_dig_toggle": True, "n_actions": 5})
+    env.reset(seed=21)
+    op = O.default_params(allow_dig_toggle=1)
+    planes, envs = O.new_state(B, 10, 10)
+    O.reset(planes, envs, seed=21, params=op)
+    rng = np.random.default_rng(2)
+    ok = np.ones(B, dtype=bool)
+    for t in range(120):
+        a = rng.integers(0, 5, size=B).astype(np.int8)
+        on_fire = planes[np.arange(B), envs["y"], envs["x"], 0] == 1
+        ok &= ~((a == 4) & ((envs["flags"] & O.F_DIGGING) == 0) & on_fire)
+        _, r, d, _ = env.step(a)
+        ro, do = O.step(planes, envs, a, op)
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp[ok], planes[ok], err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge)[ok], envs[ok], err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(r[ok], ro[ok])
+    assert ok.sum() > B * 0.9
+    env.close()
+
+
+def test_auto_reset_matches_oracle_reset(wf):
+    B = 256
+    env = wf.BatchedForestFire(B, size=10, seed=31, auto_reset=True, fuel_range=(3, 9))
+    env.reset(seed=31)
+    op = O.default_params(fuel_lo=3, fuel_hi=9)
+    planes, envs = O.new_state(B, 10, 10)
+    O.reset(planes, envs, seed=31, params=op)
+    rng = np.random.default_rng(6)
+    resets = 0
+    for t in range(80):
+        a = rng.integers(0, 4, size=B).astype(np.int8)
+        _, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op)
+        if stopped.any():           # next-step autoreset: the step resets instead, reward 0, done 0
+            O.reset(planes, envs, seed=31, mask=stopped, params=op)
+            ro[stopped], do[stopped] = 0.0, 0
+            resets += int(stopped.sum())
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(r, ro)
+        np.testing.assert_array_equal(d, do.astype(bool))
+    assert resets > B
+    env.close()
+
+
+def test_frozen_after_done_and_reset_mask(wf):
+    B = 64
+    env = wf.BatchedForestFire(B, size=10, fuel_range=(2, 4))
+    env.reset(seed=1)
+    for _ in range(40):
+        _, r, d, _ = env.step(None)
+    assert d.all()
+    p0, e0 = env.download()
+    _, r, d, _ = env.step(np.zeros(B, dtype=np.int8))
+    p1, e1 = env.download()
+    np.testing.assert_array_equal(p0, p1)
+    assert (r == 0).all() and d.all()
+    mask = np.zeros(B, dtype=np.uint8)
+    mask[::2] = 1
+    env.reset(mask=mask, seed=2)
+    p2, e2 = env.download()
+    np.testing.assert_array_equal(p2[1::2], p1[1::2])
+    assert ((e2["flags"][::2] & 16) != 0).all() and ((e2["flags"][1::2] & 16) == 0).all()
+    assert (e2["episode"][::2] == 2).all() and (e2["episode"][1::2] == 1).all()
+    env.close()
+
+
+def test_edge_moves_rejected_and_agent_plane_blank(wf):
+    """Rejected move blanks the agent_pos plane until the next successful move
+    (environment.py:142); water is not traversable (:229-230)."""
+    S = 10
+    planes = np.zeros((1, S, S, 4), dtype=np.int8)
+    planes[..., 1] = 20
+    planes[0, 5, 5, 0], planes[0, 5, 5, 2] = 1, 25
+    planes[0, 0, 0, 0], planes[0, 0, 0, 3] = 3, 1          # agent in the corner on dirt
+    planes[0, 0, 1, 0] = 4                                  # water to the east
+    env = wf.BatchedForestFire(1, size=S)
+    env.upload(planes)
+    o = planes.copy()
+    oe = env.envs_from_planes(planes).astype(O.ENV_DTYPE)
+    for a in (0, 3, 2, 1, 0):   # N (oob), W (oob), E (water), S (ok), N (back)
+        obs, r, d, _ = env.step(np.array([a], dtype=np.int8))
+        O.step(o, oe, np.array([a], dtype=np.int8))
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, o)
+        np.testing.assert_array_equal(_envs(ge), oe)
+        if a in (0, 3, 2):      # rejected: agent stays in the corner, plane blank
+            assert (ge["x"][0], ge["y"][0]) == (0, 0) and gp[0, :, :, 3].sum() == 0
+    assert (gp[0, :, :, 3].sum() == 1) and gp[0, 0, 0, 3] == 1
+    env.close()
+
+
+# ------------------------------------------------------- single-env adapter (drop-in)
+def test_adapter_replays_reference_noop_episode(wf):
+    """np.random.seed(0); sim.reset() spawns where the reference does, and the whole
+    no-op episode (state, reward, done per step) matches the reference fixture."""
+    import random
+    for size in (10, 14):
+        ep = Episodes([f for f in fixture_files(size) if f.endswith("_noop.npz")][0])
+        sim = wf.ForestFire(size=size)
+        np.random.seed(0)
+        random.seed(0)
+        state = sim.reset()
+        assert (sim.W.agents[0].x, sim.W.agents[0].y) == tuple(ep.d["init_agent"][0, :2])
+        assert state.shape == (size, size, 3) and state.dtype == np.float64
+        total = 0
+        for t in range(ep.T):
+            state, reward, done, info = sim.step(" ")
+            np.testing.assert_array_equal(state, ep.d["obs"][t].astype(np.float64))
+            assert reward == ep.d["reward"][t] and done == bool(ep.d["done"][t]) and info == {}
+            total += reward
+        assert done and not sim.W.RUNNING and total == ep.d["reward"].sum()
+        assert sim.W.WIDTH == size and sim.W.DEPTH == 3 and sim.n_actions == 4
+        txt = sim.render()
+        assert txt.count("\n") == size + 1 and "#" in txt
+        sim.close()
+
+
+def test_adapter_string_and_int_actions(wf):
+    sim = wf.ForestFire(size=10)
+    np.random.seed(5)
+    sim.reset()
+    x0, y0 = sim.W.agents[0].x, sim.W.agents[0].y
+    sim.step("E")
+    assert (sim.W.agents[0].x, sim.W.agents[0].y) == (x0 + 1, y0)
+    sim.step(3)
+    assert (sim.W.agents[0].x, sim.W.agents[0].y) == (x0, y0)
+    sim.step(np.int64(1))
+    assert (sim.W.agents[0].x, sim.W.agents[0].y) == (x0, y0 + 1)
+    assert sim.W.env.shape == (10, 10, 9) and sim.W.env[x0, y0, 0] == 3
+    assert not sim.W.agents[0].fire_in_direction(0) or True
+    assert len(sim.W.border_points) == 40
+    sim.close()
+
+
+# --------------------------------------------------------- full-size properties (C3)
+def test_full_size_properties_65536x14x14(wf):
+    """BASELINE config 3 at full size: (i) determinism - two contexts fed the same
+    inputs agree bit for bit; (ii) shard independence - env i behaves the same inside
+    a 65536-batch and inside a 4096-batch holding global ids [8192, 12288);
+    (iii) conservation laws of the rule; (iv) a strided sample equals the oracle."""
+    B, S, T = 65536, 14, 24
+    a = np.random.default_rng(0).integers(0, 4, size=(T, B)).astype(np.int8)
+    big = wf.BatchedForestFire(B, size=S, seed=3, fuel_range=(10, 40))
+    big2 = wf.BatchedForestFire(B, size=S, seed=3, fuel_range=(10, 40))
+    small = wf.BatchedForestFire(4096, size=S, seed=3, fuel_range=(10, 40), env_id0=8192)
+    for e in (big, big2, small):
+        e.reset(seed=3)
+    p0, e0 = big.download()
+    idx = np.arange(0, B, 512)
+    op = O.default_params(fuel_lo=10, fuel_hi=40)
+    sp, se = np.ascontiguousarray(p0[idx]), np.ascontiguousarray(e0[idx]).astype(O.ENV_DTYPE)
+    se["flags"] &= VIS
+    prev = p0
+    for t0 in range(0, T, 8):
+        rb, db = big.step_many(a[t0:t0 + 8])
+        rb2, _ = big2.step_many(a[t0:t0 + 8])
+        rs, _ = small.step_many(a[t0:t0 + 8, 8192:12288])
+        np.testing.assert_array_equal(rb, rb2)
+        np.testing.assert_array_equal(rb[:, 8192:12288], rs)
+        for k in range(8):
+            ro, _ = O.step(sp, se, a[t0 + k, idx], op)
+            np.testing.assert_array_equal(rb[k, idx], ro)
+        p, e = big.download()
+        np.testing.assert_array_equal(p[idx], sp)
+        # fuel never increases, heat never decreases on grass, burnt/dirt are absorbing
+        assert (p[..., 1] <= prev[..., 1]).all()
+        assert ((prev[..., 0] == 2) <= (p[..., 0] >= 2)).all()
+        assert ((prev[..., 0] == 3) <= (p[..., 0] == 3)).all()
+        assert (p[..., 2] >= prev[..., 2]).all()
+        assert (p[..., 3].reshape(B, -1).sum(axis=1) <= 1).all()
+        prev = p
+    ps, es = small.download()
+    np.testing.assert_array_equal(prev[8192:12288], ps)
+    p2, _ = big2.download()
+    np.testing.assert_array_equal(prev, p2)
+    for e in (big, big2, small):
+        e.close()

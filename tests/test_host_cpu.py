@@ -1,0 +1,162 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol,
+host logic (tables, ignition count, action vocabulary, sharding) is right, and the
+product path fails loudly - never falls back - when no device is present."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import wildfire_control_python_amd as pkg
+from wildfire_control_python_amd import _native as N
+from wildfire_control_python_amd import utility as U
+from oracle import oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "wildfire_control_python_amd", "csrc")])
+    lib = N.lib()
+    header = open(os.path.join(REPO, "include", "wildfire.h")).read()
+    declared = set(re.findall(r"\b(wf_[a-z_]+)\s*\(", header))
+    declared -= {"wf_status"}
+    bound = {s[0] for s in N.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wf_abi_version() == 1
+    assert lib.wf_strerror(-3).decode().startswith("no usable HIP device")
+
+
+def test_default_params_match_reference_constants():
+    p = N.default_params()
+    assert (p.ignite_count, p.allow_dig_toggle, p.containment, p.auto_reset) == (19, 0, 1, 0)
+    assert (p.death_penalty, p.contained_bonus, p.default_reward) == (-1000.0, 1000.0, -1.0)
+    assert (p.fuel_lo, p.fuel_hi, p.ignite_ppm) == (20, 20, 0)
+    assert ctypes.sizeof(N.Params) == 72 and N.ENV_DTYPE.itemsize == 16
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device error path")
+def test_no_device_fails_loudly_without_fallback():
+    with pytest.raises(N.WildfireError) as ei:
+        pkg.BatchedForestFire(8, size=14)
+    assert ei.value.status == -3
+    with pytest.raises(N.WildfireError):
+        pkg.ForestFire(size=10)
+
+
+def test_bad_arguments_rejected_before_touching_a_device():
+    lib = N.lib()
+    h = ctypes.c_void_p()
+    p = N.default_params()
+    assert lib.wf_create(ctypes.byref(h), 0, 0, 14, 14, ctypes.byref(p)) == -1       # batch 0
+    assert lib.wf_create(ctypes.byref(h), 0, 4, 11, 11, ctypes.byref(p)) == -2       # unsupported shape
+    p.ignite_count = 0
+    assert lib.wf_create(ctypes.byref(h), 0, 4, 14, 14, ctypes.byref(p)) == -1
+    assert lib.wf_step(None, None, 1, 1, None, None) == -1
+    assert lib.wf_destroy(None) == -1
+
+
+def test_ignite_count_is_the_float64_threshold_crossing():
+    assert U.ignite_count(0.54) == 19          # 18*0.162 = 2.916 <= 3 < 19*0.162
+    q, t = U.heat_quantum(0.54), 0.0
+    for n in range(1, 20):
+        t += q
+        assert (t > 3) == (n >= 19)
+    assert U.ignite_count(0.7) == 15 and U.ignite_count(0.85) == 12
+    assert U.temp_from_count(25, 0.54) == 4.0 and U.temp_from_count(19, 0.54) == t
+
+
+def test_circle_points_agree_with_oracle_restatement():
+    for r in (1, 2, 3):
+        assert U.circle_points(0, 0, r) == O.circle_points(r)
+    assert U.get_fire_location(10, 10) == (5, 5) and U.get_fire_location(14, 14) == (7, 7)
+    np.random.seed(0)
+    locs = {U.get_agent_location(10, 10) for _ in range(400)}
+    assert len(locs) == 36                      # 8 + 12 + 16 distinct spawn points
+
+
+def test_action_vocabulary():
+    enc = pkg.encode_action
+    assert [enc(a) for a in ("N", "S", "E", "W", "D", " ", "x")] == [0, 1, 2, 3, 4, 5, 5]
+    assert [enc(a) for a in (0, 1, 2, 3, 4, 5, -1, np.int64(2), None)] == [0, 1, 2, 3, 4, 5, 5, 2, 5]
+
+
+def test_metadata_is_a_per_env_copy_with_reference_keys():
+    from wildfire_control_python_amd.constants import METADATA
+    assert METADATA["wind"] == [0.54, (0, 0)] and METADATA["n_actions"] == 4
+    assert METADATA["contained_bonus"] == 1000 and METADATA["death_penalty"] == -1000
+    assert set(U.layer) == {"type", "gray", "temp", "heat", "fuel", "threshold", "agent_pos",
+                            "fire_mobility", "agent_mobility"}
+    assert U.types["dirt"] == 3 and U.types[4] == "water"
+    assert set(U.color2ascii.values()) == {"+", "@", "#", "0", "x"}
+
+
+def test_shard_bounds_partition_the_batch():
+    for gb, w in ((1_000_000, 8), (65536 * 4, 4), (10, 3), (7, 8)):
+        spans = [pkg.shard_bounds(gb, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert pkg.shard_bounds(1_000_000, 8, 3) == (375000, 500000)    # env id -> GPU = id // 125000
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    GB, S = 96, 10
+    lo, hi = pkg.shard_bounds(GB, world, rank)
+    # each rank resets + steps ONLY its shard (oracle as the CPU stand-in for the kernel),
+    # keyed by global env ids; no data-path collective
+    planes, envs = O.new_state(hi - lo, S, S)
+    p = O.default_params(fuel_lo=10, fuel_hi=40)
+    O.reset(planes, envs, seed=5, env_id0=lo, params=p)
+    sys.path.insert(0, REPO)
+    import bench
+    acts = bench.make_actions(30, lo, hi, 5)
+    for t in range(30):
+        O.step(planes, envs, acts[t], p)
+    # bench's only collective: max over ranks of the elapsed time
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((rank, lo, hi, planes, float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_is_shard_count_independent():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[4] for r in res] == [2.0, 2.0]
+    sharded = np.concatenate([r[3] for r in res])
+    # single-"GPU" run of the same global batch
+    import bench
+    planes, envs = O.new_state(96, 10, 10)
+    p = O.default_params(fuel_lo=10, fuel_hi=40)
+    O.reset(planes, envs, seed=5, params=p)
+    acts = bench.make_actions(30, 0, 96, 5)
+    for t in range(30):
+        O.step(planes, envs, acts[t], p)
+    np.testing.assert_array_equal(sharded, planes)

@@ -1,0 +1,252 @@
+"""BatchedForestFire: many independent forest-fire environments stepped in lock-step
+on one MI355X through the C-ABI of include/wildfire.h.
+
+Same verbs as the reference environment facade (Simulation/forest_fire.py:18-54):
+``reset() -> state``, ``step(action) -> [state, reward, done, {}]``, ``get_state()``,
+with a leading batch axis on everything.  State lives in HBM as one int8
+(batch, H, W, 4) buffer; nothing here computes a cell update on the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+from .constants import METADATA as _DEFAULT_METADATA
+from .utility import (get_agent_location, get_fire_location, get_name, grass, ignite_count,
+                      layer)
+
+_ACTION_CODES = {"N": 0, "S": 1, "E": 2, "W": 3, "D": 4}
+NOOP = 5
+
+
+def encode_action(a):
+    """Reference action vocabulary (forest_fire.py:32-36): "N","S","E","W" or 0..3 move,
+    "D" or 4 toggles digging (when allowed); anything else does nothing."""
+    if isinstance(a, str):
+        return _ACTION_CODES.get(a, NOOP)
+    try:
+        if a in range(5):
+            return int(a)
+    except TypeError:
+        pass
+    return NOOP
+
+
+class BatchedForestFire:
+    def __init__(self, batch, size=None, *, width=None, height=None, device=0, metadata=None,
+                 seed=0, env_id0=0, auto_reset=False, fuel_range=None, ignite_ppm=0,
+                 containment=True):
+        self.METADATA = dict(_DEFAULT_METADATA)
+        if metadata:
+            self.METADATA.update(metadata)
+        if size is not None:
+            width = height = size
+        if width is not None:
+            self.METADATA["width"] = int(width)
+        if height is not None:
+            self.METADATA["height"] = int(height)
+        self.width, self.height = self.METADATA["width"], self.METADATA["height"]
+        self.batch = int(batch)
+        self.device = int(device)
+        self.DEBUG = self.METADATA["debug"]
+        self.layer = layer
+        self.get_name = get_name
+        self.n_actions = self.METADATA["n_actions"]
+        self.seed = int(seed)
+        self._reset_count = 0
+
+        wind = self.METADATA["wind"]
+        if wind == "random" or tuple(wind[1]) != (0, 0):
+            # environment.py:188-190: direction-dependent addends summed in Python set order;
+            # the reference itself is not bit-reproducible there - out of parity scope.
+            raise NotImplementedError("only wind vector (0, 0) has an exact integer restatement")
+        if self.METADATA["make_rivers"]:
+            raise NotImplementedError("make_rivers: upload planes with water cells instead")
+        self.wind_speed, self.wind_vector = wind[0], tuple(wind[1])
+
+        p = N.default_params()
+        p.ignite_count = ignite_count(self.wind_speed)
+        p.allow_dig_toggle = int(bool(self.METADATA["allow_dig_toggle"]))
+        p.containment = int(bool(containment))
+        p.auto_reset = int(bool(auto_reset))
+        p.death_penalty = float(self.METADATA["death_penalty"])
+        p.contained_bonus = float(self.METADATA["contained_bonus"])
+        p.default_reward = float(self.METADATA["default_reward"])
+        lo, hi = fuel_range if fuel_range is not None else (grass["fuel"], grass["fuel"])
+        p.fuel_lo, p.fuel_hi = int(lo), int(hi)
+        p.ignite_ppm = int(ignite_ppm)
+        p.seed = self.seed
+        p.env_id0 = int(env_id0)
+        self.params = p
+
+        self._lib = N.lib()
+        h = ctypes.c_void_p()
+        rc = self._lib.wf_create(ctypes.byref(h), self.device, self.batch, self.height,
+                                 self.width, ctypes.byref(p))
+        if rc != N.WF_OK:
+            raise N.WildfireError(rc, f"wf_create(batch={batch}, H={self.height}, W={self.width})")
+        self._h = h
+        self.kernel_name = self._lib.wf_kernel_name(self._h).decode()
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc, where):
+        if rc != N.WF_OK:
+            raise N.WildfireError(rc, where, self._lib.wf_last_hip_error(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.wf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._ck(self._lib.wf_set_stream(self._h, ctypes.c_void_p(int(hip_stream))), "wf_set_stream")
+
+    def sync(self):
+        self._ck(self._lib.wf_sync(self._h), "wf_sync")
+
+    @property
+    def planes_ptr(self):
+        return self._lib.wf_planes_device(self._h)
+
+    @property
+    def envs_ptr(self):
+        return self._lib.wf_envs_device(self._h)
+
+    # ------------------------------------------------------------- state exchange
+    def upload(self, planes=None, envs=None):
+        """Replace device state.  planes int8 (batch,H,W,4); envs _native.ENV_DTYPE (batch,).
+        When envs is omitted it is derived from the planes the way Agent.__init__ does
+        (environment.py:103-109): the agent is where the agent_pos plane says."""
+        if planes is not None:
+            planes = np.ascontiguousarray(planes, dtype=np.int8)
+            assert planes.shape == (self.batch, self.height, self.width, 4), planes.shape
+            if envs is None:
+                envs = self.envs_from_planes(planes)
+        if envs is not None:
+            envs = np.ascontiguousarray(envs, dtype=N.ENV_DTYPE)
+            assert envs.shape == (self.batch,)
+        self._ck(self._lib.wf_upload(self._h, N.ptr(planes), N.ptr(envs)), "wf_upload")
+
+    def download(self):
+        planes = np.empty((self.batch, self.height, self.width, 4), dtype=np.int8)
+        envs = np.empty(self.batch, dtype=N.ENV_DTYPE)
+        self._ck(self._lib.wf_download(self._h, N.ptr(planes), N.ptr(envs)), "wf_download")
+        return planes, envs
+
+    def envs_from_planes(self, planes):
+        envs = np.zeros(self.batch, dtype=N.ENV_DTYPE)
+        ag = planes[..., N.P_AGENT] != 0
+        has = ag.reshape(self.batch, -1).any(axis=1)
+        idx = ag.reshape(self.batch, -1).argmax(axis=1)
+        envs["x"] = np.where(has, idx % self.width, 0)
+        envs["y"] = np.where(has, idx // self.width, 0)
+        fire = (planes[..., N.P_TYPE] == N.FIRE).reshape(self.batch, -1).any(axis=1)
+        envs["flags"] = (has * (N.F_ALIVE | N.F_VISIBLE | N.F_DIGGING)) | ((has & fire) * N.F_RUNNING)
+        return envs
+
+    # ----------------------------------------------------------------------- reset
+    def reset(self, mask=None, seed=None):
+        """World.reset() (environment.py:186-212) on the device for every env (or the
+        masked ones), spawn points from the counter-based stream.  Returns the state."""
+        if seed is None:
+            seed = self.seed + 0x9E3779B9 * self._reset_count
+        self._reset_count += 1
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.shape == (self.batch,)
+        self._ck(self._lib.wf_reset(self._h, N.ptr(mask), ctypes.c_uint64(int(seed) & (2**64 - 1))),
+                 "wf_reset")
+        self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
+        return self.get_state()
+
+    def reset_host(self, spawns=None, rng=np.random):
+        """World.reset() built on the host and uploaded: spawn points either given
+        ((batch,2) x,y) or drawn from numpy's legacy stream in the reference's own
+        order (utility.py:66-78), so a seeded run spawns where the reference does."""
+        B, H, W = self.batch, self.height, self.width
+        planes = np.zeros((B, H, W, 4), dtype=np.int8)
+        planes[..., N.P_FUEL] = grass["fuel"]                              # reset_map :63
+        fx, fy = get_fire_location(W, H)
+        planes[:, fy, fx, N.P_TYPE] = N.FIRE                               # set_fire_to :233-246
+        planes[:, fy, fx, N.P_HEAT] = N.HEAT_FORCED
+        envs = np.zeros(B, dtype=N.ENV_DTYPE)
+        for b in range(B):
+            sx, sy = spawns[b] if spawns is not None else get_agent_location(W, H, rng)
+            planes[b, sy, sx, N.P_AGENT] = 1                               # Agent.__init__ :108-113
+            planes[b, sy, sx, N.P_TYPE] = N.DIRT
+            envs[b]["x"], envs[b]["y"] = sx, sy
+        envs["flags"] = N.F_ALIVE | N.F_VISIBLE | N.F_DIGGING | N.F_RUNNING
+        self.upload(planes, envs)
+        self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
+        return self.get_state()
+
+    # ------------------------------------------------------------------------ step
+    def _update_mask(self, n_steps):
+        m = 0
+        md = self.METADATA
+        for s in range(n_steps):                                           # forest_fire.py:40-43
+            md["a_speed_iter"] -= 1
+            if md["a_speed_iter"] == 0:
+                m |= 1 << s
+                md["a_speed_iter"] = md["a_speed"]
+        return m
+
+    def step_many(self, actions=None, n_steps=None):
+        """n_steps fused ForestFire.step() calls in ONE kernel launch (the grid stays in
+        registers between ticks).  actions int8 (n_steps, batch) or None for no-ops.
+        Returns (reward float64 (n_steps,batch), done bool (n_steps,batch))."""
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.int8)
+            if actions.ndim == 1:
+                actions = actions[None, :]
+            assert actions.shape[1] == self.batch
+            n_steps = actions.shape[0]
+        n_steps = int(n_steps or 1)
+        reward = np.empty((n_steps, self.batch), dtype=np.float64)
+        done = np.empty((n_steps, self.batch), dtype=np.uint8)
+        mask = self._update_mask(n_steps)
+        self._ck(self._lib.wf_step(self._h, N.ptr(actions), n_steps, ctypes.c_uint64(mask),
+                                   N.ptr(reward), N.ptr(done)), "wf_step")
+        return reward, done.astype(bool)
+
+    def step(self, actions=None):
+        """[state (batch,W,H,3) int8, reward float64 (batch,), done bool (batch,), {}]
+        (forest_fire.py:30-49 with a batch axis)."""
+        if actions is not None and not isinstance(actions, np.ndarray):
+            actions = np.array([encode_action(a) for a in actions], dtype=np.int8)
+        reward, done = self.step_many(actions, 1)
+        return [self.get_state(), reward[0], done[0], {}]
+
+    def step_device(self, d_actions=None, n_steps=1, d_reward=None, d_done=None, update_mask=None):
+        """Asynchronous step on device buffers (torch tensors or raw pointers)."""
+        if update_mask is None:
+            update_mask = self._update_mask(n_steps)
+        self._ck(self._lib.wf_step_device(self._h, N.ptr(d_actions), int(n_steps),
+                                          ctypes.c_uint64(update_mask), N.ptr(d_reward), N.ptr(d_done)),
+                 "wf_step_device")
+
+    # ----------------------------------------------------------------- observation
+    def get_state(self):
+        """World.get_state() (environment.py:399-402): int8 (batch, W, H, 3), [b, x, y, k]."""
+        obs = np.empty((self.batch, self.width, self.height, 3), dtype=np.int8)
+        self._ck(self._lib.wf_get_state(self._h, N.ptr(obs)), "wf_get_state")
+        return obs
+
+    def get_state_device(self, d_obs):
+        self._ck(self._lib.wf_get_state_device(self._h, N.ptr(d_obs)), "wf_get_state_device")
+
+    # ---------------------------------------------------------------------- timing
+    def timer_start(self):
+        self._ck(self._lib.wf_timer_start(self._h), "wf_timer_start")
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        self._ck(self._lib.wf_timer_stop(self._h, ctypes.byref(ms)), "wf_timer_stop")
+        return float(ms.value)

@@ -1,0 +1,383 @@
+// wf_abi.cpp - host side of the C-ABI declared in include/wildfire.h.
+//
+// Owns the device state of a batch of environments (planes, env scalars,
+// containment bitboards, staging buffers) and launches the gfx950 kernels of
+// wf_kernels.hip on the context's HIP stream.  There is NO CPU fallback: without a
+// usable HIP device wf_create fails with WF_ERR_NO_DEVICE.
+#include <new>
+#include <string.h>
+
+#include "wf_internal.h"
+
+struct wf_ctx {
+    int device = 0;
+    int batch = 0, H = 0, W = 0;
+    int num_cus = 256;
+    wf_params p;
+    WfFamily fam = WF_FAM_NONE;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // device state
+    uint32_t *planes = nullptr;       // (batch, H*W) dwords
+    uint32_t *planes_alt = nullptr;   // tiled path ping-pong
+    wf_env *envs = nullptr;
+    u64 *reach = nullptr;
+    // device staging for the host-buffer entry points (grown on demand)
+    int8_t *d_actions = nullptr;
+    double *d_reward = nullptr;
+    uint8_t *d_done = nullptr;
+    uint8_t *d_mask = nullptr;
+    int8_t *d_obs = nullptr;
+    int staged_steps = 0;
+    WfSpawn spawn;
+    int last_hip = 0;
+};
+
+namespace {
+
+int fail(wf_ctx *c, hipError_t e)
+{
+    if (c) c->last_hip = (int)e;
+    return e == hipErrorOutOfMemory ? WF_ERR_NOMEM : WF_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, expr)                                 \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return fail((ctx), _e);      \
+    } while (0)
+
+// circle_points(r) around the origin, in the reference's generation order
+// (midpoint circle algorithm, Simulation/utility.py:8-52).
+int circle_points(int r, int8_t *dx, int8_t *dy)
+{
+    int n = 0;
+    auto put = [&](int a, int b) { dx[n] = (int8_t)a; dy[n] = (int8_t)b; ++n; };
+    int x = r, y = 0;
+    put(x, y);
+    if (r > 0) { put(-x, -y); put(y, -x); put(-y, x); }
+    int P = 1 - r;
+    while (x > y) {
+        ++y;
+        if (P <= 0) {
+            P += 2 * y + 1;
+        } else {
+            --x;
+            P += 2 * y - 2 * x + 1;
+        }
+        if (x < y) break;
+        put(x, y); put(-x, y); put(x, -y); put(-x, -y);
+        if (x != y) { put(y, x); put(-y, x); put(y, -x); put(-y, -x); }
+    }
+    return n;
+}
+
+bool params_ok(const wf_params *p)
+{
+    if (p->ignite_count < 1 || p->ignite_count >= WF_HEAT_FORCED) return false;
+    if (p->fuel_lo < 1 || p->fuel_hi < p->fuel_lo || p->fuel_hi > 127) return false;
+    if (p->ignite_ppm > 1000000u) return false;
+    return true;
+}
+
+WfArgs base_args(const wf_ctx *c)
+{
+    WfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.planes = c->planes;
+    a.planes_out = c->planes_alt ? c->planes_alt : c->planes;
+    a.envs = c->envs;
+    a.reach = c->reach;
+    a.batch = c->batch;
+    a.H = c->H;
+    a.W = c->W;
+    a.n_steps = 1;
+    a.update_mask = ~0ull;
+    a.p = c->p;
+    a.spawn = c->spawn;
+    return a;
+}
+
+int ensure_staging(wf_ctx *c, int n_steps)
+{
+    if (n_steps <= c->staged_steps) return WF_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->d_actions) (void)hipFree(c->d_actions);
+    if (c->d_reward) (void)hipFree(c->d_reward);
+    if (c->d_done) (void)hipFree(c->d_done);
+    c->d_actions = nullptr; c->d_reward = nullptr; c->d_done = nullptr;
+    c->staged_steps = 0;
+    const size_t n = (size_t)n_steps * (size_t)c->batch;
+    HIP_TRY(c, hipMalloc((void **)&c->d_actions, n));
+    HIP_TRY(c, hipMalloc((void **)&c->d_reward, n * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_done, n));
+    c->staged_steps = n_steps;
+    return WF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wf_abi_version(void) { return WF_ABI_VERSION; }
+
+void wf_default_params(wf_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->ignite_count = 19;          // 18 x 0.162 = 2.916 <= 3 < 19 x 0.162 (constants.py:39, utility.py:98-100)
+    p->allow_dig_toggle = 0;       // constants.py:46
+    p->containment = 1;
+    p->auto_reset = 0;
+    p->death_penalty = -1000.0;    // constants.py:32
+    p->contained_bonus = 1000.0;   // constants.py:33
+    p->default_reward = -1.0;      // constants.py:34
+    p->fuel_lo = 20;               // utility.py:99
+    p->fuel_hi = 20;
+    p->ignite_ppm = 0;
+    p->seed = 0;
+    p->env_id0 = 0;
+}
+
+const char *wf_strerror(int status)
+{
+    switch (status) {
+    case WF_OK: return "ok";
+    case WF_ERR_ARG: return "invalid argument";
+    case WF_ERR_UNSUPPORTED: return "grid shape or option not supported by this build";
+    case WF_ERR_NO_DEVICE: return "no usable HIP device (the wildfire step has no CPU fallback)";
+    case WF_ERR_HIP: return "HIP runtime error (see wf_last_hip_error)";
+    case WF_ERR_NOMEM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+int wf_last_hip_error(const wf_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params *p)
+{
+    if (!out) return WF_ERR_ARG;
+    *out = nullptr;
+    if (batch < 1 || H < 1 || W < 1 || H > 65535 || W > 65535) return WF_ERR_ARG;
+    wf_params pp;
+    if (p) pp = *p; else wf_default_params(&pp);
+    if (!params_ok(&pp)) return WF_ERR_ARG;
+    const WfFamily fam = wf_pick_family(H, W);
+    if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return WF_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return WF_ERR_ARG;
+
+    wf_ctx *c = new (std::nothrow) wf_ctx();
+    if (!c) return WF_ERR_NOMEM;
+    c->device = device;
+    c->batch = batch;
+    c->H = H;
+    c->W = W;
+    c->p = pp;
+    c->fam = fam;
+    for (int r = 0; r < 3; ++r) c->spawn.n[r] = circle_points(r + 1, c->spawn.dx[r], c->spawn.dy[r]);
+
+    int rc = WF_OK;
+    hipError_t e;
+    do {
+        if ((e = hipSetDevice(device)) != hipSuccess) break;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) break;
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) break;
+        c->own_stream = true;
+        if ((e = hipEventCreate(&c->ev0)) != hipSuccess) break;
+        if ((e = hipEventCreate(&c->ev1)) != hipSuccess) break;
+        const size_t cells = (size_t)batch * H * W;
+        if ((e = hipMalloc((void **)&c->planes, cells * 4)) != hipSuccess) break;
+        if (fam == WF_FAM_TILED && (e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&c->reach, (size_t)batch * 4 * sizeof(u64))) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&c->d_mask, (size_t)batch)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(c->planes, 0, cells * 4, c->stream)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(c->envs, 0, (size_t)batch * sizeof(wf_env), c->stream)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(c->reach, 0, (size_t)batch * 4 * sizeof(u64), c->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess) {
+        rc = fail(c, e);
+        wf_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return WF_OK;
+}
+
+int wf_destroy(wf_ctx *c)
+{
+    if (!c) return WF_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_actions, c->d_reward,
+                     c->d_done, c->d_mask, c->d_obs };
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return WF_OK;
+}
+
+int wf_set_params(wf_ctx *c, const wf_params *p)
+{
+    if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
+    c->p = *p;
+    return WF_OK;
+}
+
+int wf_set_stream(wf_ctx *c, void *hip_stream)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return WF_OK;
+}
+
+int wf_upload(wf_ctx *c, const int8_t *planes, const wf_env *envs)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t cells = (size_t)c->batch * c->H * c->W;
+    if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, cells * 4, hipMemcpyHostToDevice, c->stream));
+    if (envs) HIP_TRY(c, hipMemcpyAsync(c->envs, envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyHostToDevice, c->stream));
+    if (planes || envs) HIP_TRY(c, wf_launch_invalidate_reach(c->envs, c->batch, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_download(wf_ctx *c, int8_t *planes, wf_env *envs)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t cells = (size_t)c->batch * c->H * c->W;
+    if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, cells * 4, hipMemcpyDeviceToHost, c->stream));
+    if (envs) HIP_TRY(c, hipMemcpyAsync(envs, c->envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_reset_device(wf_ctx *c, const uint8_t *d_mask, uint64_t seed)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    WfArgs a = base_args(c);
+    a.mask = d_mask;
+    a.reset_seed = seed;
+    HIP_TRY(c, wf_launch_reset(c->fam, a, c->stream, c->num_cus));
+    return WF_OK;
+}
+
+int wf_reset(wf_ctx *c, const uint8_t *mask, uint64_t seed)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (mask) HIP_TRY(c, hipMemcpyAsync(c->d_mask, mask, (size_t)c->batch, hipMemcpyHostToDevice, c->stream));
+    int rc = wf_reset_device(c, mask ? c->d_mask : nullptr, seed);
+    if (rc != WF_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_step_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t update_mask,
+                   double *d_reward, uint8_t *d_done)
+{
+    if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    WfArgs a = base_args(c);
+    a.actions = d_actions;
+    a.reward = d_reward;
+    a.done = d_done;
+    a.n_steps = n_steps;
+    a.update_mask = update_mask;
+    HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
+    if (c->fam == WF_FAM_TILED) {   // ping-pong: the freshly written buffer becomes current
+        uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t;
+    }
+    return WF_OK;
+}
+
+int wf_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
+            double *reward, uint8_t *done)
+{
+    if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
+    int rc = ensure_staging(c, n_steps);
+    if (rc != WF_OK) return rc;
+    const size_t n = (size_t)n_steps * (size_t)c->batch;
+    if (actions) HIP_TRY(c, hipMemcpyAsync(c->d_actions, actions, n, hipMemcpyHostToDevice, c->stream));
+    rc = wf_step_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask,
+                        reward ? c->d_reward : nullptr, done ? c->d_done : nullptr);
+    if (rc != WF_OK) return rc;
+    if (reward) HIP_TRY(c, hipMemcpyAsync(reward, c->d_reward, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (done) HIP_TRY(c, hipMemcpyAsync(done, c->d_done, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_get_state_device(wf_ctx *c, int8_t *d_obs)
+{
+    if (!c || !d_obs) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, wf_launch_get_state(c->planes, d_obs, c->batch, c->H, c->W, c->stream));
+    return WF_OK;
+}
+
+int wf_get_state(wf_ctx *c, int8_t *obs)
+{
+    if (!c || !obs) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->batch * c->H * c->W * 3;
+    if (!c->d_obs) HIP_TRY(c, hipMalloc((void **)&c->d_obs, n));
+    int rc = wf_get_state_device(c, c->d_obs);
+    if (rc != WF_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_sync(wf_ctx *c)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+void *wf_planes_device(wf_ctx *c) { return c ? (void *)c->planes : nullptr; }
+void *wf_envs_device(wf_ctx *c) { return c ? (void *)c->envs : nullptr; }
+
+int wf_timer_start(wf_ctx *c)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    return WF_OK;
+}
+
+int wf_timer_stop(wf_ctx *c, float *elapsed_ms)
+{
+    if (!c || !elapsed_ms) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return WF_OK;
+}
+
+const char *wf_kernel_name(const wf_ctx *c)
+{
+    return c ? wf_family_name(c->fam, c->H, c->W) : "none";
+}
+
+}  // extern "C"

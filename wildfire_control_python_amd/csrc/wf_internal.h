@@ -1,0 +1,48 @@
+// wf_internal.h - shared between the C-ABI host code (wf_abi.cpp) and the gfx950
+// kernels (wf_kernels.hip).  Not part of the public boundary (include/wildfire.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wildfire.h"
+
+typedef unsigned long long u64;
+
+// Agent spawn table: circle_points(r) of reference Simulation/utility.py:8-52 for
+// r = 1,2,3 (8 / 12 / 16 points), offsets relative to the fire location.
+struct WfSpawn {
+    int8_t dx[3][16];
+    int8_t dy[3][16];
+    int32_t n[3];
+};
+
+// Everything a step / reset launch needs, passed by value (kernarg segment).
+struct WfArgs {
+    uint32_t *planes;        // (batch, H*W) one dword per cell
+    uint32_t *planes_out;    // tiled path: ping-pong target (== planes for the wave path)
+    wf_env *envs;            // (batch)
+    u64 *reach;              // (batch, 4) border-reachability bitboards (wave path)
+    const int8_t *actions;   // (n_steps, batch) or nullptr
+    double *reward;          // (n_steps, batch) or nullptr
+    uint8_t *done;           // (n_steps, batch) or nullptr
+    const uint8_t *mask;     // reset: per-env mask or nullptr
+    int32_t batch, H, W, n_steps;
+    u64 update_mask;
+    wf_params p;
+    u64 reset_seed;          // wf_reset: explicit seed (auto_reset uses p.seed)
+    WfSpawn spawn;
+};
+
+// kernel families (wf_kernels.hip)
+enum WfFamily { WF_FAM_NONE = 0, WF_FAM_WAVE = 1, WF_FAM_TILED = 2 };
+
+// Returns the family able to serve (H, W), and its name.
+WfFamily wf_pick_family(int H, int W);
+const char *wf_family_name(WfFamily f, int H, int W);
+
+// Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
+hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
+hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
+hipError_t wf_launch_invalidate_reach(wf_env *envs, int batch, hipStream_t s);
+hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, int H, int W,
+                               hipStream_t s);
