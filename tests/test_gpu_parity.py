@@ -132,8 +132,9 @@ def test_dig_toggle_matches_oracle_outside_documented_corner(wf):
     ok = np.ones(B, dtype=bool)
     for t in range(120):
         a = rng.integers(0, 5, size=B).astype(np.int8)
+        live = (envs["flags"] & (O.F_RUNNING | O.F_ALIVE)) == (O.F_RUNNING | O.F_ALIVE)
         on_fire = planes[np.arange(B), envs["y"], envs["x"], 0] == 1
-        ok &= ~((a == 4) & ((envs["flags"] & O.F_DIGGING) == 0) & on_fire)
+        ok &= ~(live & (a == 4) & ((envs["flags"] & O.F_DIGGING) == 0) & on_fire)
         _, r, d, _ = env.step(a)
         ro, do = O.step(planes, envs, a, op)
         gp, ge = env.download()
@@ -206,13 +207,13 @@ def test_edge_moves_rejected_and_agent_plane_blank(wf):
     env.upload(planes)
     o = planes.copy()
     oe = env.envs_from_planes(planes).astype(O.ENV_DTYPE)
-    for a in (0, 3, 2, 1, 0):   # N (oob), W (oob), E (water), S (ok), N (back)
+    for i, a in enumerate((0, 3, 2, 1, 0)):   # N (oob), W (oob), E (water), S (ok), N (back)
         obs, r, d, _ = env.step(np.array([a], dtype=np.int8))
         O.step(o, oe, np.array([a], dtype=np.int8))
         gp, ge = env.download()
         np.testing.assert_array_equal(gp, o)
         np.testing.assert_array_equal(_envs(ge), oe)
-        if a in (0, 3, 2):      # rejected: agent stays in the corner, plane blank
+        if i < 3:               # rejected: agent stays in the corner, plane blank
             assert (ge["x"][0], ge["y"][0]) == (0, 0) and gp[0, :, :, 3].sum() == 0
     assert (gp[0, :, :, 3].sum() == 1) and gp[0, 0, 0, 3] == 1
     env.close()

@@ -129,66 +129,15 @@ struct EnvKey {
     __device__ __forceinline__ uint32_t draw(uint32_t d) const { return hash32(k0 ^ hash32(d + k1)); }
 };
 
-// ----------------------------------------------------------------------------
-// per-wave environment state held in registers
-// ----------------------------------------------------------------------------
-struct Cells {
-    uint32_t t[4];   // type
-    int32_t f[4];    // fuel (signed int8 range)
-    uint32_t h[4];   // heat quanta
-};
-
 struct EnvS {        // wave-uniform scalars of one environment
     uint32_t ax, ay, fl, episode, tick;
 };
 
-template <int W, int H>
-__device__ __forceinline__ void unpack(const uint4 &raw, Cells &c)
-{
-    const uint32_t r[4] = { raw.x, raw.y, raw.z, raw.w };
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        c.t[j] = r[j] & 0xffu;
-        c.f[j] = (int32_t)(int8_t)(r[j] >> 8);
-        c.h[j] = (r[j] >> 16) & 0xffu;
-    }
-}
-
-template <int W, int H>
-__device__ __forceinline__ uint4 pack(const Cells &c, const EnvS &s, int lane)
-{
-    const uint32_t qa = s.ay * W + s.ax;
-    const bool here = (s.fl & WF_F_VISIBLE) && (uint32_t)lane == (qa >> 2);
-    uint32_t r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t ag = (here && (qa & 3u) == (uint32_t)j) ? (1u << 24) : 0u;
-        r[j] = c.t[j] | (((uint32_t)c.f[j] & 0xffu) << 8) | (c.h[j] << 16) | ag;
-    }
-    return make_uint4(r[0], r[1], r[2], r[3]);
-}
-
-// type of cell q (q wave-uniform)
-__device__ __forceinline__ uint32_t type_at(const Cells &c, uint32_t q)
-{
-    const uint32_t k = q & 3u;
-    const uint32_t v = k == 0 ? c.t[0] : k == 1 ? c.t[1] : k == 2 ? c.t[2] : c.t[3];
-    return __builtin_amdgcn_readlane(v, q >> 2);
-}
-
-__device__ __forceinline__ void set_type_at(Cells &c, uint32_t q, uint32_t ty, int lane)
-{
-    const bool here = (uint32_t)lane == (q >> 2);
-    const uint32_t k = q & 3u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        c.t[j] = (here && k == (uint32_t)j) ? ty : c.t[j];
-}
-
 // World.reset() into registers (environment.py:186-212, reset_map :59-67,
 // get_agent_location utility.py:66-78) with the counter-based stream.
 template <int W, int H>
-__device__ __forceinline__ void reset_regs(const WfArgs &a, u64 seed, int e, int lane, Cells &c, EnvS &s)
+__device__ __forceinline__ void reset_regs(const WfArgs &a, u64 seed, int e, int lane,
+                                           uint32_t (&t)[4], uint32_t (&u)[4], uint32_t (&h)[4], EnvS &s)
 {
     constexpr int CELLS = W * H;
     const EnvKey key(seed, a.p.env_id0 + (u64)e, s.episode);
@@ -213,9 +162,9 @@ __device__ __forceinline__ void reset_regs(const WfArgs &a, u64 seed, int e, int
             extra = ty == WF_GRASS && below(key.draw(16u + CELLS + q), 1000000u) < a.p.ignite_ppm;
         if (extra) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }
         onborder |= __ballot(extra && active) & CM<W, H, j>::BORDER;
-        c.t[j] = active ? ty : 0u;
-        c.f[j] = active ? fuel : 0;
-        c.h[j] = active ? heat : 0u;
+        t[j] = active ? ty : (uint32_t)WF_DIRT;
+        u[j] = active ? ((uint32_t)fuel & 0xffu) : 0u;
+        h[j] = active ? heat : 0u;
     });
     s.ax = sx;
     s.ay = sy;
@@ -241,245 +190,257 @@ __device__ __forceinline__ void flood(u64 (&R)[4], const u64 (&P)[4])
     }
 }
 
-// Number of maximal runs of passable cells on the 8-cell ring around cell q
-// (cyclic order N,NE,E,SE,S,SW,W,NW; off-grid = impassable).  Removing q from the
-// passable set can only change connectivity between its neighbours when that
-// number is >= 2.  Lanes 0..7 each look at one ring cell (ds_bpermute gather).
-template <int W, int H>
-__device__ __forceinline__ int ring_runs(const Cells &c, uint32_t q, int lane)
-{
-    const int x = (int)(q % W), y = (int)(q / W);
-    const int k = lane & 7;
-    // dx+1 / dy+1 packed 2 bits per ring position
-    const int dx = (int)((0x01A9u >> (2 * k)) & 3u) - 1;   // 0,1,1,1,0,-1,-1,-1 -> 1,2,2,2,1,0,0,0
-    const int dy = (int)((0x1A90u >> (2 * k)) & 3u) - 1;   // -1,-1,0,1,1,1,0,-1 -> 0,0,1,2,2,2,1,0
-    const int nx = x + dx, ny = y + dy;
-    const bool in = (unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H;
-    const uint32_t nq = in ? (uint32_t)(ny * W + nx) : 0u;
-    const uint32_t tp = c.t[0] | (c.t[1] << 8) | (c.t[2] << 16) | (c.t[3] << 24);
-    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nq >> 2) << 2), (int)tp);
-    const uint32_t ty = (v >> (8u * (nq & 3u))) & 0xffu;
-    const uint32_t ring = (uint32_t)(__ballot(in && ty < WF_DIRT && lane < 8)) & 0xffu;
-    const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
-    return __popc(ring & ~rot);
-}
+// Containment shortcut used by the step kernel: removing a cell q from the passable
+// set can only change which cells are connected to the border when q is itself a
+// border cell, or when the passable cells on the 8-cell ring around q (cyclic order
+// N,NE,E,SE,S,SW,W,NW; off-grid = impassable) form >= 2 separate runs.  Otherwise any
+// path through q re-routes along the single run.  Lanes 0..7 each inspect one ring
+// cell (ds_bpermute gather of the packed types).
 
 // ----------------------------------------------------------------------------
 // the step kernel: n_steps x ForestFire.step() (forest_fire.py:30-49) per env
 // ----------------------------------------------------------------------------
+// Work split inside a wave (the scalar unit is one instruction per clock for the
+// whole CU, the four SIMDs together issue two vector instructions per clock):
+//   scalar unit : only the 64-bit mask algebra (neighbour shifts, reachability
+//                 bitboards, any/or reductions) and the rare uniform branches;
+//   vector unit : the per-cell rule AND the per-environment flag logic, the latter
+//                 branch-free on values that are identical in all 64 lanes.
+typedef const u64 __attribute__((address_space(4))) *const_u64_ptr;
+
+// move table, 6 bits per action 0..4: (dx+1) | (dy+1)<<2 | is_move<<4; entry 4 = "no move"
+// (N=(0,-1) S=(0,+1) E=(+1,0) W=(-1,0): environment.py:163-171)
+constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 | (2u | 1u << 2 | 16u) << 12 |
+                              (0u | 1u << 2 | 16u) << 18 | (1u | 1u << 2) << 24;
+
+__device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+__device__ __forceinline__ uint32_t pack_types(const uint32_t (&t)[4])
+{
+    return t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+}
+// type of cell q, q identical in all lanes but held in a VGPR
+__device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
+{
+    return __builtin_amdgcn_ubfe(bperm(q >> 2, tp), (q & 3u) << 3, 8u);
+}
+
 template <int W, int H>
 __global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
 {
     constexpr int CELLS = W * H, LANES = CELLS / 4;
-    constexpr u64 VALID = CM<W, H, 0>::VALID;
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = __lane_id();
     const int wave0 = (int)rfl(blockIdx.x * 4u + (threadIdx.x >> 6));
     const int nwaves = (int)gridDim.x * 4;
-    const bool active = lane < LANES;
+    const bool active = lane < (uint32_t)LANES;
     const uint32_t ign = (uint32_t)a.p.ignite_count;
+    const uint4 *planes4 = reinterpret_cast<const uint4 *>(a.planes);
+    // ring geometry for the containment shortcut: lanes 0..7 <-> N,NE,E,SE,S,SW,W,NW
+    const uint32_t rk = lane & 7u;
+    const int rdx = (int)((0x01A9u >> (2u * rk)) & 3u) - 1;
+    const int rdy = (int)((0x1A90u >> (2u * rk)) & 3u) - 1;
+
+    uint4 raw_next = make_uint4(0, 0, 0, 0);
+    if (wave0 < a.batch && active) raw_next = planes4[(size_t)wave0 * LANES + lane];
 
     for (int e = wave0; e < a.batch; e += nwaves) {
-        // ---- environment scalars (one 16-byte record, same address in every lane)
+        const uint4 raw = raw_next;
+        {   // software prefetch of this wave's next environment
+            const int en = e + nwaves;
+            if (en < a.batch && active) raw_next = planes4[(size_t)en * LANES + lane];
+        }
+        // env record: same 16 bytes in every lane, kept in VGPRs on purpose
         const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
-        EnvS s;
+        uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu, episode = ev.z, tick = ev.w;
+        uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[e] : 0xffu;
+        // border-reachability bitboards through the scalar cache
+        u64 RB[4];
         {
-            const uint32_t xy = rfl(ev.x);
-            s.ax = xy & 0xffffu;
-            s.ay = xy >> 16;
-            s.fl = rfl(ev.y) & 0xffffu;
-            s.episode = rfl(ev.z);
-            s.tick = rfl(ev.w);
+            const_u64_ptr rp = (const_u64_ptr)(uintptr_t)(a.reach + (size_t)e * 4);
+            RB[0] = rp[0]; RB[1] = rp[1]; RB[2] = rp[2]; RB[3] = rp[3];
         }
-        uint4 *gp = reinterpret_cast<uint4 *>(a.planes + (size_t)e * CELLS) + lane;
-        Cells c;
-        bool dirty = false;
-        if (s.fl & WF_F_RUNNING) {
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            if (active) raw = *gp;
-            unpack<W, H>(raw, c);
-        } else {
+        uint32_t t[4], u[4], h[4];           // type, fuel (unsigned byte), heat quanta
+        {
+            const uint32_t r[4] = { raw.x, raw.y, raw.z, raw.w };
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { c.t[j] = 0; c.f[j] = 0; c.h[j] = 0; }
+            for (int j = 0; j < 4; ++j) {
+                t[j] = active ? (r[j] & 0xffu) : (uint32_t)WF_DIRT;   // idle lanes: inert, impassable
+                u[j] = (r[j] >> 8) & 0xffu;
+                h[j] = (r[j] >> 16) & 0xffu;
+            }
         }
-        u64 RB[4] = { 0, 0, 0, 0 };          // cells connected to a passable border cell
-        bool rb_loaded = false, rb_dirty = false;
+        bool dirty = false, rb_dirty = false;
 
         for (int st = 0; st < a.n_steps; ++st) {
             const size_t oi = (size_t)st * (size_t)a.batch + (size_t)e;
-            double reward = 0.0;
-            bool done;
-            if (!(s.fl & WF_F_RUNNING)) {
+            uint32_t act_next = 0xffu;
+            if (st + 1 < a.n_steps && a.actions) act_next = (uint32_t)(uint8_t)a.actions[oi + (size_t)a.batch];
+
+            if (rfl(fl & WF_F_RUNNING) == 0u) {
+                // ---- rare: finished environment
+                bool done = true;
                 if (a.p.auto_reset) {
                     // gymnasium-style next-step autoreset: this step returns the fresh episode
-                    reset_regs<W, H>(a, a.p.seed, e, lane, c, s);
+                    EnvS s = { rfl(ax), rfl(ay), rfl(fl), rfl(episode), rfl(tick) };
+                    reset_regs<W, H>(a, a.p.seed, e, (int)lane, t, u, h, s);
+                    ax = s.ax; ay = s.ay; fl = s.fl; episode = s.episode; tick = s.tick;
                     dirty = true;
-                    rb_loaded = true;        // nothing to load: the bitboard is invalid (flag cleared)
                     done = false;
-                } else {
-                    done = true;             // frozen: the reference is never stepped after done
                 }
                 if (lane == 0) {
-                    if (a.reward) a.reward[oi] = reward;
+                    if (a.reward) a.reward[oi] = 0.0;
                     if (a.done) a.done[oi] = done ? 1 : 0;
                 }
+                act = act_next;
                 continue;
             }
             dirty = true;
-            const int act = a.actions ? (int)(int8_t)rfl((uint32_t)a.actions[oi]) : -1;
-            const bool do_update = (a.update_mask >> st) & 1ull;
 
-            // ---- Agent.move (environment.py:141-155)
-            bool dug = false;
-            uint32_t qdug = 0;
-            if ((unsigned)act < 4u) {
-                s.fl &= ~(uint32_t)WF_F_VISIBLE;                                  // :142
-                const int nx = (int)s.ax + (act == 2) - (act == 3);                // :163-171
-                const int ny = (int)s.ay + (act == 1) - (act == 0);
-                if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {    // :146 inbounds
-                    const uint32_t qd = (uint32_t)(ny * W + nx);
-                    const uint32_t td = type_at(c, qd);
-                    if (td != WF_WATER) {                                          // :146 traversable
-                        s.ax = (uint32_t)nx;                                       // :148-149
-                        s.ay = (uint32_t)ny;
-                        s.fl |= WF_F_VISIBLE;
-                        if (td == WF_FIRE) {
-                            s.fl |= WF_F_DEAD;                                     // :154-155
-                        } else if ((s.fl & WF_F_DIGGING) && td != WF_DIRT) {       // :151-152, :125-133
-                            dug = true;
-                            qdug = qd;
-                        }
-                    }
+            // ---- Agent.move (environment.py:141-155).  Integer 0/1 flags on the vector
+            // unit only: combining per-lane booleans would cost 64-bit scalar mask ops.
+            const uint32_t ent = MOVE_LUT >> (min(act, 4u) * 6u);                  // act is an unsigned byte
+            const uint32_t ism = (ent >> 4) & 1u;                                  // action in N,S,E,W
+            const uint32_t nx = ax + (ent & 3u) - 1u;                              // :163-171
+            const uint32_t ny = ay + ((ent >> 2) & 3u) - 1u;
+            const uint32_t out = (((uint32_t)(W - 1) - nx) | nx | ((uint32_t)(H - 1) - ny) | ny) >> 31;
+            const uint32_t inb = ism & (out ^ 1u);                                 // :146 inbounds
+            const uint32_t qa = ay * W + ax;
+            uint32_t qd = qa + inb * (ny * W + nx - qa);
+            const uint32_t tp = pack_types(t);
+            const uint32_t td = type_of(tp, qd);
+            const uint32_t tcur = type_of(tp, qa);
+            const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u);         // :146 traversable
+            const uint32_t dfire = moved & (2u >> td);                             // destination burning
+            uint32_t dug = moved & (fl >> 2) & (5u >> td) & 1u;                    // digging, grass|burnt (:151-152, :125-133)
+            fl = (fl & ~(ism << 1)) | (moved << 1) | (dfire << 3);                 // :142, :148-149, :154-155
+            ax += moved * (nx - ax);
+            ay += moved * (ny - ay);
+            uint32_t ta = tcur + moved * (td - tcur);                              // type under the agent
+            // ---- Agent.toggle_digging (forest_fire.py:35-36, environment.py:136-138): rare
+            if (a.p.allow_dig_toggle) {
+                if (rfl(act == 4u ? 1u : 0u)) {
+                    fl ^= WF_F_DIGGING;
+                    // divergence (documented): the reference also retypes a BURNING cell to dirt
+                    // here while keeping it in burning_cells; this build leaves it burning.
+                    dug = (fl >> 2) & (5u >> tcur) & 1u;
+                    qd = qa;
                 }
             }
-            // ---- Agent.toggle_digging (forest_fire.py:35-36, environment.py:136-138)
-            if (a.p.allow_dig_toggle && act == 4) {
-                s.fl ^= WF_F_DIGGING;
-                if (s.fl & WF_F_DIGGING) {
-                    const uint32_t qa = s.ay * W + s.ax;
-                    const uint32_t ta = type_at(c, qa);
-                    // divergence (documented): the reference also retypes a BURNING cell to
-                    // dirt here while keeping it in burning_cells; this build leaves it burning.
-                    if (ta != WF_DIRT && ta != WF_FIRE) { dug = true; qdug = qa; }
-                }
+            ta += dug * ((uint32_t)WF_DIRT - ta);
+            {
+                // per-lane selector: component to retype on the owning lane, >= 4 elsewhere
+                const uint32_t sel = (qd & 3u) + ((min((qd >> 2) ^ lane, 1u) | (dug ^ 1u)) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = (sel == (uint32_t)j) ? (uint32_t)WF_DIRT : t[j];
             }
-            if (dug) set_type_at(c, qdug, WF_DIRT, lane);
 
             // ---- ForestFire.update (forest_fire.py:85-106)
-            u64 FIRE[4], GRASS[4], NEWFIRE[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                FIRE[j] = __ballot(c.t[j] == WF_FIRE);
-                GRASS[j] = __ballot(c.t[j] == WF_GRASS) & VALID;
-            }
+            u64 NEWFIRE[4];
+            const bool do_update = (a.update_mask >> st) & 1ull;
             if (do_update) {
-                if (s.fl & WF_F_ALIVE) {                                           // :87, is_dead :116-120
-                    const uint32_t qa = s.ay * W + s.ax;
-                    const bool onfire = (sel4(FIRE, (int)(qa & 3u)) >> (qa >> 2)) & 1ull;
-                    if ((s.fl & WF_F_DEAD) || onfire)
-                        s.fl &= ~(uint32_t)(WF_F_ALIVE | WF_F_VISIBLE);
-                }
+                // :87 drop dead agents (Agent.is_dead environment.py:116-120)
+                const uint32_t dies = fl & ((fl >> 3) | (2u >> ta)) & 1u;          // alive & (dead | on fire)
+                fl &= ~(dies * (uint32_t)(WF_F_ALIVE | WF_F_VISIBLE));
+
                 u64 STILL[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    STILL[j] = FIRE[j] & __ballot(c.f[j] > 1);                    // reduce_fuel :297-307
-                    c.f[j] -= lanebit(FIRE[j]) ? 1 : 0;
+                    // reduce_fuel (:297-307): a fire cell whose fuel-1 > 0 keeps burning
+                    const uint32_t key = (t[j] << 8) + u[j];
+                    STILL[j] = __ballot((key - 0x102u) < 0x7Eu);                   // t==1 && 2<=fuel<=127
+                    const uint32_t isfire = (2u >> t[j]) & 1u;
+                    u[j] = (u[j] - isfire) & 0xffu;
+                    t[j] += isfire;                                                // fire -> burnt ...
                 }
                 u64 border_hit = 0;
                 static_for<4>([&](auto J) {
                     constexpr int j = decltype(J)::value;
+                    t[j] -= lanebit(STILL[j]) ? 1u : 0u;                           // ... unless still burning
                     // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294)
-                    const uint32_t cnt = (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) +
-                                         (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
-                                         (lanebit(nb_lf<W, H, j>(STILL)) ? 1u : 0u) +
-                                         (lanebit(nb_rt<W, H, j>(STILL)) ? 1u : 0u);
-                    const uint32_t hn = c.h[j] + cnt;
-                    const u64 IGN = GRASS[j] & __ballot(hn >= ign);
-                    c.h[j] = lanebit(GRASS[j]) ? min(hn, ign) : c.h[j];
-                    c.t[j] = lanebit(FIRE[j] & ~STILL[j]) ? (uint32_t)WF_BURNT
-                           : lanebit(IGN)                ? (uint32_t)WF_FIRE : c.t[j];
+                    const uint32_t hn = h[j] + (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) +
+                                               (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
+                                               (lanebit(nb_lf<W, H, j>(STILL)) ? 1u : 0u) +
+                                               (lanebit(nb_rt<W, H, j>(STILL)) ? 1u : 0u);
+                    const uint32_t key2 = (t[j] << 8) + hn;
+                    const u64 IGN = __ballot((key2 - ign) < (256u - ign));         // grass && hn >= ign
+                    h[j] = (t[j] == WF_GRASS) ? min(hn, ign) : h[j];
+                    t[j] += lanebit(IGN) ? 1u : 0u;                                // grass -> fire
                     border_hit |= IGN & CM<W, H, j>::BORDER;                       // set_fire_to :245-246
                     NEWFIRE[j] = STILL[j] | IGN;
-                    GRASS[j] &= ~IGN;
                 });
-                if (border_hit) s.fl |= WF_F_BORDER;
-                s.tick += 1;
+                fl |= border_hit ? (uint32_t)WF_F_BORDER : 0u;
+                tick += 1;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) NEWFIRE[j] = FIRE[j];
+                for (int j = 0; j < 4; ++j) NEWFIRE[j] = __ballot(t[j] == WF_FIRE);
             }
-            const bool anyfire = (NEWFIRE[0] | NEWFIRE[1] | NEWFIRE[2] | NEWFIRE[3]) != 0;
-            if (do_update && (!(s.fl & WF_F_ALIVE) || !anyfire))
-                s.fl &= ~(uint32_t)WF_F_RUNNING;                                   // :105-106
+            const uint32_t anyfire = (NEWFIRE[0] | NEWFIRE[1] | NEWFIRE[2] | NEWFIRE[3]) ? 1u : 0u;   // wave-uniform
+            if (do_update)
+                fl &= ~(((fl & anyfire) ^ 1u) << 4);                               // :105-106 (!alive || !fire) -> !RUNNING
 
             // ---- World.get_reward (environment.py:342-390)
-            bool paid = false;
-            bool rb_updated = false;
-            if (a.p.containment && !(s.fl & (WF_F_BORDER | WF_F_CONTAINED)) && anyfire) {   // :345-346
-                u64 PASS[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) PASS[j] = VALID & ~__ballot(c.t[j] >= WF_DIRT);
-                if (!rb_loaded) {
-                    if (s.fl & WF_F_REACH_VALID) {
-                        const uint32_t v = lane < 8 ? reinterpret_cast<const uint32_t *>(a.reach)[(size_t)e * 8 + lane] : 0u;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            RB[j] = (u64)__builtin_amdgcn_readlane(v, 2 * j) |
-                                    ((u64)__builtin_amdgcn_readlane(v, 2 * j + 1) << 32);
-                    }
-                    rb_loaded = true;
+            uint32_t contained = 0;
+            // :345-346  containment test runs while the fire has not touched the border
+            const uint32_t check = (uint32_t)(a.p.containment != 0) & anyfire & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
+            if (rfl(check)) {
+                // A dug cell can only cut the fire off from the border when it is a border cell
+                // itself or when the passable cells on its 8-ring form >= 2 runs (see above).
+                uint32_t recompute = ((fl >> 7) ^ 1u) & 1u;                        // bitboard not valid yet
+                {
+                    const uint32_t xd = dug ? ax : 1u, yd = dug ? ay : 1u;         // dug cell == agent cell
+                    const uint32_t onb = (((xd - 1u) | (yd - 1u) | ((uint32_t)(W - 2) - xd) | ((uint32_t)(H - 2) - yd)) >> 31);
+                    const uint32_t rx = xd + (uint32_t)rdx, ry = yd + (uint32_t)rdy;
+                    const uint32_t rout = (((uint32_t)(W - 1) - rx) | rx | ((uint32_t)(H - 1) - ry) | ry) >> 31;
+                    const uint32_t nq = (rout ^ 1u) * (ry * W + rx);
+                    const uint32_t ty = type_of(pack_types(t), nq);
+                    const uint32_t ring = (uint32_t)__ballot((ty + 4u * rout + 4u * (lane >> 3)) < (uint32_t)WF_DIRT) & 0xffu;
+                    const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
+                    const uint32_t runs = (uint32_t)__popc(ring & ~rot);
+                    recompute |= dug & (onb | (runs >> 1) | (runs >> 2));
                 }
-                bool recompute = !(s.fl & WF_F_REACH_VALID);
-                if (!recompute && dug) {
-                    const int kd = (int)(qdug & 3u);
-                    const u64 bit = 1ull << (qdug >> 2);
-                    if (sel4(RB, kd) & bit) {
-                        const uint32_t xd = qdug % W, yd = qdug / W;
-                        const bool onb = xd == 0 || yd == 0 || xd == W - 1 || yd == H - 1;
-                        if (onb || ring_runs<W, H>(c, qdug, lane) >= 2) {
-                            recompute = true;
-                        } else {
+                if (rfl(recompute)) {
+                    u64 PASS[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) RB[j] &= ~(kd == j ? bit : 0ull);
-                            rb_dirty = true;
-                        }
-                    }
-                }
-                if (recompute) {
+                    for (int j = 0; j < 4; ++j) PASS[j] = ~__ballot(t[j] >= WF_DIRT);
                     static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                     flood<W, H>(RB, PASS);
-                    s.fl |= WF_F_REACH_VALID;
+                    fl |= WF_F_REACH_VALID;
                     rb_dirty = true;
                 }
-                rb_updated = true;
-                if (!((NEWFIRE[0] & RB[0]) | (NEWFIRE[1] & RB[1]) | (NEWFIRE[2] & RB[2]) | (NEWFIRE[3] & RB[3]))) {
-                    s.fl |= WF_F_CONTAINED;                                        // :361-367
-                    reward = a.p.contained_bonus;
-                    paid = true;
-                }
+                // stale RB bits on cells dug since the last flood are harmless: fire never sits there
+                contained = ((NEWFIRE[0] & RB[0]) | (NEWFIRE[1] & RB[1]) | (NEWFIRE[2] & RB[2]) | (NEWFIRE[3] & RB[3])) ? 0u : 1u;
+                fl |= contained << 6;                                              // :361-367
+            } else {
+                fl &= ~(dug << 7);                                                 // bitboard no longer trustworthy
             }
-            if (dug && !rb_updated) s.fl &= ~(uint32_t)WF_F_REACH_VALID;
-            if (!paid) {
-                if (!(s.fl & WF_F_ALIVE)) {
-                    reward = a.p.death_penalty;                                    // :380-381
-                } else if (!anyfire) {                                             // :384-387
-                    const int healthy = __popcll(GRASS[0]) + __popcll(GRASS[1]) + __popcll(GRASS[2]) + __popcll(GRASS[3]);
-                    reward = a.p.contained_bonus * ((double)healthy / (double)CELLS);
-                } else {
-                    reward = a.p.default_reward;                                   // :390
-                }
+            double reward = a.p.default_reward;                                    // :390
+            if (rfl(anyfire ^ 1u)) {                                               // :384-387 burnt out (rare)
+                int healthy = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) healthy += __popcll(__ballot(t[j] == WF_GRASS));
+                reward = a.p.contained_bonus * ((double)healthy / (double)CELLS);
             }
-            done = !(s.fl & WF_F_RUNNING);                                         // forest_fire.py:48
+            reward = (fl & WF_F_ALIVE) ? reward : a.p.death_penalty;               // :380-381
+            reward = contained ? a.p.contained_bonus : reward;
             if (lane == 0) {
                 if (a.reward) a.reward[oi] = reward;
-                if (a.done) a.done[oi] = done ? 1 : 0;
+                if (a.done) a.done[oi] = (uint8_t)(((fl >> 4) & 1u) ^ 1u);          // forest_fire.py:48
             }
+            act = act_next;
         }
 
         if (dirty) {
-            const uint4 out = pack<W, H>(c, s, lane);
-            if (active) *gp = out;
+            const uint32_t qa = ay * W + ax;
+            const uint32_t sel = ((fl & WF_F_VISIBLE) && lane == (qa >> 2)) ? (qa & 3u) : 4u;
+            uint32_t r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | (sel == (uint32_t)j ? (1u << 24) : 0u);
+            if (active) reinterpret_cast<uint4 *>(a.planes)[(size_t)e * LANES + lane] = make_uint4(r[0], r[1], r[2], r[3]);
             if (lane == 0) {
-                *reinterpret_cast<uint4 *>(&a.envs[e]) = make_uint4(s.ax | (s.ay << 16), s.fl, s.episode, s.tick);
+                *reinterpret_cast<uint4 *>(&a.envs[e]) = make_uint4(ax | (ay << 16), fl, episode, tick);
                 if (rb_dirty) {
                     ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(a.reach + (size_t)e * 4);
                     rp[0] = make_ulonglong2(RB[0], RB[1]);
@@ -489,6 +450,7 @@ __global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
         }
     }
 }
+
 
 // World.reset() for masked envs (environment.py:186-212)
 template <int W, int H>
@@ -506,10 +468,16 @@ __global__ __launch_bounds__(256) void wf_reset_wave(const WfArgs a)
         s.fl = 0;
         s.episode = rfl(ev.z);
         s.tick = 0;
-        Cells c;
-        reset_regs<W, H>(a, a.reset_seed, e, lane, c, s);
-        const uint4 out = pack<W, H>(c, s, lane);
-        if (lane < LANES) reinterpret_cast<uint4 *>(a.planes + (size_t)e * CELLS)[lane] = out;
+        uint32_t t[4], u[4], h[4];
+        reset_regs<W, H>(a, a.reset_seed, e, lane, t, u, h, s);
+        const uint32_t qa = s.ay * W + s.ax;
+        uint32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j] = t[j] | (u[j] << 8) | (h[j] << 16) |
+                   (((uint32_t)lane == (qa >> 2) && (qa & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
+        if (lane < LANES)
+            reinterpret_cast<uint4 *>(a.planes + (size_t)e * CELLS)[lane] = make_uint4(r[0], r[1], r[2], r[3]);
         if (lane == 0)
             *reinterpret_cast<uint4 *>(&a.envs[e]) = make_uint4(s.ax | (s.ay << 16), s.fl, s.episode, s.tick);
     }
