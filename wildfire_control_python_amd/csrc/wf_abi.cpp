@@ -29,6 +29,7 @@ struct wf_ctx {
     uint8_t *d_done = nullptr;
     uint8_t *d_mask = nullptr;
     int8_t *d_obs = nullptr;
+    WfCold *d_cold = nullptr;         // device copy of {params, spawn table} for the kernels' rare paths
     int staged_steps = 0;
     WfSpawn spawn;
     int last_hip = 0;
@@ -89,14 +90,30 @@ WfArgs base_args(const wf_ctx *c)
     a.planes_out = c->planes_alt ? c->planes_alt : c->planes;
     a.envs = c->envs;
     a.reach = c->reach;
+    a.cold = c->d_cold;
     a.batch = c->batch;
     a.H = c->H;
     a.W = c->W;
     a.n_steps = 1;
     a.update_mask = ~0ull;
-    a.p = c->p;
-    a.spawn = c->spawn;
+    a.ignite_count = c->p.ignite_count;
+    a.hot_flags = (c->p.containment ? WF_HOT_CONTAINMENT : 0) | (c->p.auto_reset ? WF_HOT_AUTO_RESET : 0) |
+                  (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0);
+    a.default_reward = c->p.default_reward;
+    a.death_penalty = c->p.death_penalty;
+    a.contained_bonus = c->p.contained_bonus;
     return a;
+}
+
+// (re)publish the rarely needed parameters to the device
+int push_cold(wf_ctx *c)
+{
+    WfCold h;
+    memset(&h, 0, sizeof(h));
+    h.p = c->p;
+    h.spawn = c->spawn;
+    HIP_TRY(c, hipMemcpy(c->d_cold, &h, sizeof(h), hipMemcpyHostToDevice));
+    return WF_OK;
 }
 
 int ensure_staging(wf_ctx *c, int n_steps)
@@ -165,6 +182,8 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (!params_ok(&pp)) return WF_ERR_ARG;
     const WfFamily fam = wf_pick_family(H, W);
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
+    // the wave kernels address the planes with 32-bit byte offsets
+    if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return WF_ERR_NO_DEVICE;
@@ -197,6 +216,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->reach, (size_t)batch * 4 * sizeof(u64))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_mask, (size_t)batch)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&c->d_cold, sizeof(WfCold))) != hipSuccess) break;
         if ((e = hipMemsetAsync(c->planes, 0, cells * 4, c->stream)) != hipSuccess) break;
         if ((e = hipMemsetAsync(c->envs, 0, (size_t)batch * sizeof(wf_env), c->stream)) != hipSuccess) break;
         if ((e = hipMemsetAsync(c->reach, 0, (size_t)batch * 4 * sizeof(u64), c->stream)) != hipSuccess) break;
@@ -204,6 +224,10 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     } while (0);
     if (e != hipSuccess) {
         rc = fail(c, e);
+        wf_destroy(c);
+        return rc;
+    }
+    if ((rc = push_cold(c)) != WF_OK) {
         wf_destroy(c);
         return rc;
     }
@@ -217,7 +241,7 @@ int wf_destroy(wf_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_actions, c->d_reward,
-                     c->d_done, c->d_mask, c->d_obs };
+                     c->d_done, c->d_mask, c->d_obs, c->d_cold };
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -230,8 +254,10 @@ int wf_destroy(wf_ctx *c)
 int wf_set_params(wf_ctx *c, const wf_params *p)
 {
     if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->p = *p;
-    return WF_OK;
+    return push_cold(c);
 }
 
 int wf_set_stream(wf_ctx *c, void *hip_stream)

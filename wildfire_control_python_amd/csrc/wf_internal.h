@@ -14,9 +14,20 @@ struct WfSpawn {
     int8_t dx[3][16];
     int8_t dy[3][16];
     int32_t n[3];
+    int32_t pad;
 };
 
-// Everything a step / reset launch needs, passed by value (kernarg segment).
+// Rarely needed parameters (reset law, spawn table).  Lives in device memory and is
+// read only inside the rare branches of the kernels, so that it costs no scalar
+// registers on the hot path.
+struct WfCold {
+    wf_params p;
+    WfSpawn spawn;
+};
+
+enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4 };
+
+// Everything a step / reset launch needs on its hot path, passed by value (kernarg segment).
 struct WfArgs {
     uint32_t *planes;        // (batch, H*W) one dword per cell
     uint32_t *planes_out;    // tiled path: ping-pong target (== planes for the wave path)
@@ -26,11 +37,13 @@ struct WfArgs {
     double *reward;          // (n_steps, batch) or nullptr
     uint8_t *done;           // (n_steps, batch) or nullptr
     const uint8_t *mask;     // reset: per-env mask or nullptr
+    const WfCold *cold;      // device copy of the rarely needed parameters
     int32_t batch, H, W, n_steps;
     u64 update_mask;
-    wf_params p;
-    u64 reset_seed;          // wf_reset: explicit seed (auto_reset uses p.seed)
-    WfSpawn spawn;
+    u64 reset_seed;          // wf_reset: explicit seed (auto_reset uses cold->p.seed)
+    int32_t ignite_count;
+    int32_t hot_flags;       // WF_HOT_*
+    double default_reward, death_penalty, contained_bonus;
 };
 
 // kernel families (wf_kernels.hip)
