@@ -43,6 +43,8 @@ struct WfArgs {
     u64 reset_seed;          // wf_reset: explicit seed (auto_reset uses cold->p.seed)
     int32_t ignite_count;
     int32_t hot_flags;       // WF_HOT_*
+    int32_t group;           // single-step group kernel: environments per wave
+    int32_t pad0;
     double default_reward, death_penalty, contained_bonus;
 };
 

@@ -226,8 +226,11 @@ constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 |
 // off-grid = impassable) form >= 2 separate runs.  Otherwise any path through q
 // re-routes along the single run.  Lanes 0..7 each inspect one ring cell.
 
+#ifndef WF_LB
+#define WF_LB 6   // minimum waves per SIMD the register allocator must leave room for
+#endif
 template <int W, int H, bool FUSED>
-__global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
+__global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
 {
     constexpr int CELLS = W * H, LANES = CELLS / 4;
     const uint32_t lane = __lane_id();
@@ -243,35 +246,42 @@ __global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
     const uint32_t rdy = ((0x1A90u >> (2u * rk)) & 3u) - 1u;
     // per-lane geometry constants (one VGPR each, computed once per wave): for the lane's
     // cell j, nx0[j] = 1 unless x == 0, nxl[j] = 1 unless x == W-1, bmask bit j = border cell.
-    uint32_t nx0[4], nxl[4], bmask = 0;
+    // packed in ONE register `geo`: bit j = nx0[j], bit 4+j = nxl[j], bit 8+j = border cell j.
+    uint32_t geo = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t q = 4u * lane + (uint32_t)j, x = q % W, y = q / W;
-        nx0[j] = x != 0u ? 1u : 0u;
-        nxl[j] = x != (uint32_t)(W - 1) ? 1u : 0u;
-        bmask |= ((x == 0u || y == 0u || x == (uint32_t)(W - 1) || y == (uint32_t)(H - 1)) ? 1u : 0u) << j;
+        geo |= (x != 0u ? 1u : 0u) << j;
+        geo |= (x != (uint32_t)(W - 1) ? 1u : 0u) << (4 + j);
+        geo |= ((x == 0u || y == 0u || x == (uint32_t)(W - 1) || y == (uint32_t)(H - 1)) ? 1u : 0u) << (8 + j);
     }
-    // opaque: stop the optimiser from turning these back into 64-bit scalar masks
-    asm volatile("" : "+v"(nx0[0]), "+v"(nx0[1]), "+v"(nx0[2]), "+v"(nx0[3]));
-    asm volatile("" : "+v"(nxl[0]), "+v"(nxl[1]), "+v"(nxl[2]), "+v"(nxl[3]), "+v"(bmask));
+    // opaque: stop the optimiser from turning this back into 64-bit scalar masks
+    asm volatile("" : "+v"(geo));
     const uint32_t lane_off = lane * 16u;
 
-    uint4 raw_next = make_uint4(0, 0, 0, 0);
-    if (wave0 < batch && active)
-        raw_next = *reinterpret_cast<const uint4 *>(planes_b + (wave0 * (uint32_t)(CELLS * 4) + lane_off));
+    uint4 raw_next = make_uint4(0, 0, 0, 0), ev_next = make_uint4(0, 0, 0, 0);
+    uint32_t act_pref = 0xffu;
+    if (wave0 < batch) {
+        if (active) raw_next = *reinterpret_cast<const uint4 *>(planes_b + (wave0 * (uint32_t)(CELLS * 4) + lane_off));
+        ev_next = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + wave0 * 16u);
+        if (a.actions) act_pref = (uint32_t)(uint8_t)a.actions[wave0];
+    }
 
     for (uint32_t e = wave0; e < batch; e += nwaves) {
         const uint4 raw = raw_next;
-        const uint32_t poff = e * (uint32_t)(CELLS * 4) + lane_off;       // byte offset of this lane's 4 cells
-        {   // software prefetch of this wave's next environment
-            const uint32_t en = e + nwaves;
-            if (en < batch && active)
-                raw_next = *reinterpret_cast<const uint4 *>(planes_b + (en * (uint32_t)(CELLS * 4) + lane_off));
-        }
         // env record: same 16 bytes in every lane, kept in VGPRs on purpose
-        const uint4 ev = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + e * 16u);
+        const uint4 ev = ev_next;
+        uint32_t act = act_pref;
+        const uint32_t poff = e * (uint32_t)(CELLS * 4) + lane_off;       // byte offset of this lane's 4 cells
+        {   // software prefetch of this wave's next environment (grid, record, action)
+            const uint32_t en = e + nwaves;
+            if (en < batch) {
+                if (active) raw_next = *reinterpret_cast<const uint4 *>(planes_b + (en * (uint32_t)(CELLS * 4) + lane_off));
+                ev_next = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + en * 16u);
+                if (a.actions) act_pref = (uint32_t)(uint8_t)a.actions[en];
+            }
+        }
         uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu, episode = ev.z, tick = ev.w;
-        uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[e] : 0xffu;
         // The compiler knows a load from a wave-uniform address is wave-uniform and would move
         // these to scalar registers (and all the flag logic below onto the scalar unit with
         // them).  Opaque VGPR constraints keep them - deliberately - on the vector side.
@@ -385,8 +395,8 @@ __global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
                         // row-wrap guard is the per-lane constant, not a 64-bit scalar mask.
                         const u64 LF = j > 0 ? STILL[(j + 3) & 3] : (STILL[3] << 1);
                         const u64 RT = j < 3 ? STILL[(j + 1) & 3] : (STILL[0] >> 1);
-                        const uint32_t cl = C::NOT_X0 == C::VALID ? (lanebit(LF) ? 1u : 0u) : (lanebit(LF) ? nx0[j] : 0u);
-                        const uint32_t cr = C::NOT_XL == C::VALID ? (lanebit(RT) ? 1u : 0u) : (lanebit(RT) ? nxl[j] : 0u);
+                        const uint32_t cl = C::NOT_X0 == C::VALID ? (lanebit(LF) ? 1u : 0u) : (lanebit(LF) ? ((geo >> j) & 1u) : 0u);
+                        const uint32_t cr = C::NOT_XL == C::VALID ? (lanebit(RT) ? 1u : 0u) : (lanebit(RT) ? ((geo >> (4 + j)) & 1u) : 0u);
                         const uint32_t hn = h[j] + (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) +
                                                    (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) + cl + cr;
                         const uint32_t key2 = (t[j] << 8) + hn;
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
                         ign_bits |= ig << j;
                     });
                     // set_fire_to :245-246  a newly ignited border cell
-                    fl |= __ballot((ign_bits & bmask) != 0u) ? (uint32_t)WF_F_BORDER : 0u;
+                    fl |= __ballot((ign_bits & (geo >> 8)) != 0u) ? (uint32_t)WF_F_BORDER : 0u;
                     tick += 1;
                 }
                 u64 FIRE[4];
@@ -502,6 +512,255 @@ __global__ __launch_bounds__(256) void wf_step_wave(const WfArgs a)
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// single-step kernel (n_steps == 1): GROUP layout
+// ----------------------------------------------------------------------------
+// A wave owns a contiguous group of G environments and runs three phases:
+//   A  lanes = environments.  Lane k does ALL per-environment logic of env k at once
+//      for the group: Agent.move / toggle / death (environment.py:116-171), the
+//      containment ring test, and applies the two or three touched bytes (dug cell,
+//      agent_pos plane) straight to the grid in memory.  One vector instruction
+//      serves up to 64 environments instead of one.
+//   B  one environment at a time, lanes = cells (4 per lane, packed dwords as they lie
+//      in memory, no unpack/pack): the CA tick proper with ballot masks.
+//   C  lanes = environments again: flags, reward, done, records.
+// Per environment this costs ~75 vector + ~85 scalar instructions against ~310 + ~140
+// for the one-env-per-wave formulation (which remains the fused multi-step path).
+enum {
+    PB_RUNNING = 1, PB_PRECHECK = 2, PB_VALID = 4, PB_RING = 8,       // phase A -> B (per env)
+    RB_ANYFIRE = 1, RB_BORDER = 2, RB_CONTAINED = 4, RB_RECOMPUTED = 8, RB_WASRESET = 16, RB_HEALTHY_SHIFT = 8
+};
+
+template <int W, int H>
+__global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
+{
+    constexpr int CELLS = W * H, LANES = CELLS / 4;
+    constexpr uint32_t ENV_BYTES = CELLS * 4;
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = rfl(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t batch = (uint32_t)a.batch;
+    const uint32_t G = (uint32_t)a.group;
+    const uint32_t e0 = wave * G;
+    if (e0 >= batch) return;
+    const uint32_t ng = min(G, batch - e0);                 // environments in this group (wave-uniform)
+    const bool active = lane < (uint32_t)LANES;
+    const uint32_t ign = (uint32_t)a.ignite_count;
+    const bool do_update = (a.update_mask & 1ull) != 0;
+    char *planes_b = reinterpret_cast<char *>(a.planes);
+    const uint32_t lane_off = lane * 16u;
+
+    // ================= phase A: lanes = environments =================
+    const bool lane_env = lane < ng;
+    const uint32_t ek = e0 + (lane_env ? lane : 0u);        // idle lanes shadow env e0 (loads only)
+    const uint32_t pbase = ek * ENV_BYTES;
+    const uint4 ev = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + ek * 16u);
+    const uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[ek] : 0xffu;
+    uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu, episode = ev.z, tick = ev.w;
+    const uint32_t running = (fl >> 4) & 1u & (lane_env ? 1u : 0u);
+
+    // ---- Agent.move (environment.py:141-155), integer 0/1 flags
+    const uint32_t ent = MOVE_LUT >> (min(act, 4u) * 6u);
+    const uint32_t ism = (ent >> 4) & 1u;
+    const uint32_t nx = ax + (ent & 3u) - 1u;                                          // :163-171
+    const uint32_t ny = ay + ((ent >> 2) & 3u) - 1u;
+    const uint32_t out = (((uint32_t)(W - 1) - nx) | nx | ((uint32_t)(H - 1) - ny) | ny) >> 31;
+    const uint32_t inb = ism & (out ^ 1u);                                             // :146 inbounds
+    const uint32_t qa = ay * W + ax;
+    uint32_t qd = qa + inb * (ny * W + nx - qa);
+    // gathers: type byte of the destination / current cell, and of the 8-ring around the
+    // cell that would be dug (ring test, see "Containment shortcut" above)
+    const uint32_t td = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + qd * 4u));
+    const uint32_t tcur = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + qa * 4u));
+    const bool toggling = (a.hot_flags & WF_HOT_DIG_TOGGLE) != 0;
+    const uint32_t istog = toggling ? (act == 4u ? 1u : 0u) : 0u;
+    // cell that may be dug: destination of a move, or the own cell when digging is toggled on
+    const uint32_t xd = istog ? ax : (inb ? nx : ax), yd = istog ? ay : (inb ? ny : ay);
+    uint32_t ring = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        constexpr int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
+        const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
+        const uint32_t rout = (((uint32_t)(W - 1) - rx) | rx | ((uint32_t)(H - 1) - ry) | ry) >> 31;
+        const uint32_t nq = (rout ^ 1u) * (ry * W + rx);
+        const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
+        ring |= ((rout ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
+    }
+    const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u) & running;           // :146 traversable
+    const uint32_t dfire = moved & (2u >> td);                                         // destination burning
+    uint32_t dug = moved & (fl >> 2) & (5u >> td) & 1u;                                // :151-152, :125-133
+    const uint32_t vis_before = (fl >> 1) & 1u & running;
+    fl = (fl & ~((ism & running) << 1)) | (moved << 1) | (dfire << 3);                 // :142, :148-149, :154-155
+    ax += moved * (nx - ax);
+    ay += moved * (ny - ay);
+    uint32_t ta = tcur + moved * (td - tcur);                                          // type under the agent
+    {   // Agent.toggle_digging (forest_fire.py:35-36, environment.py:136-138)
+        const uint32_t tg = istog & running;
+        fl ^= tg << 2;
+        // divergence (documented): the reference also retypes a BURNING cell to dirt here
+        // while keeping it in burning_cells; this build leaves it burning.
+        const uint32_t dugt = (fl >> 2) & (5u >> tcur) & 1u;
+        dug = tg ? dugt : dug;
+        qd = tg ? qa : qd;
+    }
+    ta += dug * ((uint32_t)WF_DIRT - ta);
+    if (do_update) {   // forest_fire.py:87 drop dead agents (Agent.is_dead environment.py:116-120)
+        const uint32_t dies = fl & ((fl >> 3) | (2u >> ta)) & 1u & running;
+        fl &= ~(dies * (uint32_t)(WF_F_ALIVE | WF_F_VISIBLE));
+    }
+    const uint32_t vis_after = (fl >> 1) & 1u;
+    const uint32_t qa_new = ay * W + ax;
+    // apply the touched bytes to the grid in memory (phase B reloads the whole grid)
+    if (vis_before) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qa * 4u + 3u)) = 0;
+    if (dug) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qd * 4u)) = (uint8_t)WF_DIRT;
+    if (vis_after & running) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qa_new * 4u + 3u)) = 1;
+    // ring verdict: can this dig disconnect anything from the border?
+    uint32_t ringflag;
+    {
+        const uint32_t onb = (((xd - 1u) | (yd - 1u) | ((uint32_t)(W - 2) - xd) | ((uint32_t)(H - 2) - yd)) >> 31);
+        const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
+        const uint32_t runs = (uint32_t)__popc(ring & ~rot);
+        ringflag = dug & (onb | (runs >> 1) | (runs >> 2)) & 1u;
+    }
+    const uint32_t precheck = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
+    const uint32_t Pv = running | (precheck << 1) | (((fl >> 7) & 1u) << 2) | (ringflag << 3);
+    uint32_t Rv = 0;                                         // phase B results, one word per env-lane
+
+    // the byte stores above must have landed before phase B reads those grids back
+    __builtin_amdgcn_s_waitcnt(0);                           // vmcnt(0) lgkmcnt(0) expcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ================= phase B: one environment at a time, lanes = cells =================
+    const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
+    uint4 raw_next = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);   // idle lanes: inert, impassable
+    if (active) raw_next = *reinterpret_cast<const uint4 *>(planes_b + (e0 * ENV_BYTES + lane_off));
+    for (uint32_t k = 0; k < ng; ++k) {
+        const uint32_t e = e0 + k;
+        const uint4 raw = raw_next;
+        if (k + 1 < ng && active)
+            raw_next = *reinterpret_cast<const uint4 *>(planes_b + ((e + 1) * ENV_BYTES + lane_off));
+        const uint32_t P = __builtin_amdgcn_readlane(Pv, k);
+        uint32_t R = 0;
+        if (!(P & PB_RUNNING)) {
+            // ---- rare: finished environment
+            if (a.hot_flags & WF_HOT_AUTO_RESET) {
+                EnvS s = { 0, 0, 0, (uint32_t)__builtin_amdgcn_readlane(episode, k), 0 };
+                const WfCold *cold = a.cold;
+                uint32_t e_pin = e;
+                asm volatile("" : "+s"(cold), "+s"(e_pin));
+                cold_ptr cc = (cold_ptr)(uintptr_t)cold;
+                uint32_t t[4], u[4], h[4];
+                reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s);
+                const uint32_t qs = s.ay * W + s.ax;
+                uint32_t r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | ((lane == (qs >> 2) && (qs & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
+                if (active) *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(r[0], r[1], r[2], r[3]);
+                ax = (lane == k ? (s.ax) : ax);
+                ay = (lane == k ? (s.ay) : ay);
+                fl = (lane == k ? (s.fl) : fl);
+                episode = (lane == k ? (s.episode) : episode);
+                tick = (lane == k ? (s.tick) : tick);
+                R = RB_WASRESET;
+            }
+            Rv = (lane == k ? (R) : Rv);
+            continue;
+        }
+        uint32_t c[4] = { raw.x, raw.y, raw.z, raw.w };     // packed cells: type | fuel<<8 | heat<<16 | agent<<24
+        u64 FIRE[4];                                        // fire cells after the tick
+        if (do_update) {
+            // ---- ForestFire.update (forest_fire.py:85-106)
+            u64 STILL[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // reduce_fuel (environment.py:297-307)
+                const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+                STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
+                c[j] += lanebit(F) ? K_FIRE_STEP : 0u;                         // fuel -= 1, fire -> burnt ...
+            }
+            u64 border_hit = 0;
+            static_for<4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                using C = CM<W, H, j>;
+                c[j] -= lanebit(STILL[j]) ? 1u : 0u;                           // ... unless still burning
+                // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294), branch-free so
+                // that every mask stays a wave-uniform scalar
+                const u64 GR = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
+                const uint32_t cnt = (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
+                                     (lanebit(nb_lf<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_rt<W, H, j>(STILL)) ? 1u : 0u);
+                const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
+                const u64 IGN = GR & __ballot(cnt >= room);
+                const uint32_t cn = c[j] + (min(cnt, room) << 16) + (lanebit(IGN) ? 1u : 0u);   // heat saturates; grass -> fire
+                c[j] = lanebit(GR) ? cn : c[j];
+                border_hit |= IGN & C::BORDER;                                 // set_fire_to :245-246
+                FIRE[j] = STILL[j] | IGN;
+            });
+            R |= border_hit ? RB_BORDER : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+        }
+        const bool anyfire = (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) != 0;
+        R |= anyfire ? RB_ANYFIRE : 0u;
+        // ---- containment part of World.get_reward (environment.py:345-377)
+        if ((P & PB_PRECHECK) && anyfire && !(R & RB_BORDER)) {
+            typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+            typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
+            u64 RB[4];
+            if ((P & PB_VALID) && !(P & PB_RING)) {
+                const u64x4 rbv = *(const_u64x4_ptr)(uintptr_t)(a.reach + (size_t)e * 4);
+                RB[0] = rbv.x; RB[1] = rbv.y; RB[2] = rbv.z; RB[3] = rbv.w;
+            } else {
+                u64 PASS[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) PASS[j] = ~__ballot((c[j] & 0xffu) >= (uint32_t)WF_DIRT);
+                static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
+                flood<W, H>(RB, PASS);
+                if (lane == 0) {
+                    ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(a.reach + (size_t)e * 4);
+                    rp[0] = make_ulonglong2(RB[0], RB[1]);
+                    rp[1] = make_ulonglong2(RB[2], RB[3]);
+                }
+                R |= RB_RECOMPUTED;
+            }
+            // stale RB bits on cells dug since the last flood are harmless: fire never sits there
+            if (!((FIRE[0] & RB[0]) | (FIRE[1] & RB[1]) | (FIRE[2] & RB[2]) | (FIRE[3] & RB[3]))) R |= RB_CONTAINED;
+        }
+        if (!anyfire) {                                                        // :384-387 burnt out (rare)
+            uint32_t healthy = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) healthy += (uint32_t)__popcll(__ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS));
+            R |= healthy << RB_HEALTHY_SHIFT;
+        }
+        if (active) *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(c[0], c[1], c[2], c[3]);
+        Rv = (lane == k ? (R) : Rv);
+    }
+
+    // ================= phase C: lanes = environments =================
+    {
+        const uint32_t anyfire = Rv & 1u, bhit = (Rv >> 1) & 1u, contained = (Rv >> 2) & 1u;
+        const uint32_t recomputed = (Rv >> 3) & 1u, wasreset = (Rv >> 4) & 1u, healthy = Rv >> RB_HEALTHY_SHIFT;
+        const uint32_t upd = do_update ? running : 0u;
+        fl |= (bhit << 5) | (contained << 6) | (recomputed << 7);
+        fl &= ~((upd & ((fl & anyfire) ^ 1u)) << 4);                           // forest_fire.py:105-106
+        tick += upd;
+        double reward = a.default_reward;                                      // environment.py:390
+        if (__ballot(running && !anyfire))                                     // :384-387 (rare, wave-uniform branch)
+            reward = anyfire ? reward : a.contained_bonus * ((double)healthy / (double)CELLS);
+        reward = (fl & WF_F_ALIVE) ? reward : a.death_penalty;                 // :380-381
+        reward = contained ? a.contained_bonus : reward;                       // :361-367
+        reward = running ? reward : 0.0;                                       // finished (frozen or freshly reset)
+        const uint32_t done = wasreset ? 0u : (((fl >> 4) & 1u) ^ 1u);         // forest_fire.py:48
+        if (lane_env) {
+            if (running | wasreset)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.envs) + ek * 16u) = make_uint4(ax | (ay << 16), fl, episode, tick);
+            if (a.reward) a.reward[ek] = reward;
+            if (a.done) a.done[ek] = (uint8_t)done;
+        }
+    }
+}
+
 // World.reset() for masked envs (environment.py:186-212)
 template <int W, int H>
 __global__ __launch_bounds__(256) void wf_reset_wave(const WfArgs a)
@@ -570,8 +829,16 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.n_steps > 1)
         hipLaunchKernelGGL((wf_step_wave<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((wf_step_wave<W, H, false>), dim3(blocks), dim3(256), 0, s, a);
+    else {
+        // single step: group layout.  G environments per wave, sized so that every resident wave
+        // slot of the chip (32 per CU) gets one group.
+        WfArgs g = a;
+        int G = 1;
+        while (G < 64 && (long long)G * num_cus * 32 < a.batch) G *= 2;
+        g.group = G;
+        const int waves = (a.batch + G - 1) / G;
+        hipLaunchKernelGGL((wf_step_group<W, H>), dim3((waves + 3) / 4), dim3(256), 0, s, g);
+    }
     return hipGetLastError();
 }
 
