@@ -5,6 +5,7 @@
 // wf_kernels.hip on the context's HIP stream.  There is NO CPU fallback: without a
 // usable HIP device wf_create fails with WF_ERR_NO_DEVICE.
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 #include "wf_internal.h"
@@ -99,6 +100,10 @@ WfArgs base_args(const wf_ctx *c)
     a.ignite_count = c->p.ignite_count;
     a.hot_flags = (c->p.containment ? WF_HOT_CONTAINMENT : 0) | (c->p.auto_reset ? WF_HOT_AUTO_RESET : 0) |
                   (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0);
+    {   // experiment knob: cap on environments per wave of the single-step kernel
+        const char *g = getenv("WF_GROUP");
+        a.group = g ? atoi(g) : 0;
+    }
     a.default_reward = c->p.default_reward;
     a.death_penalty = c->p.death_penalty;
     a.contained_bonus = c->p.contained_bonus;

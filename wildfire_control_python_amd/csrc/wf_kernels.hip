@@ -631,111 +631,133 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // ================= phase B: one environment at a time, lanes = cells =================
-    const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
-    uint4 raw_next = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);   // idle lanes: inert, impassable
-    if (active) raw_next = *reinterpret_cast<const uint4 *>(planes_b + (e0 * ENV_BYTES + lane_off));
-    for (uint32_t k = 0; k < ng; ++k) {
-        const uint32_t e = e0 + k;
-        const uint4 raw = raw_next;
-        if (k + 1 < ng && active)
-            raw_next = *reinterpret_cast<const uint4 *>(planes_b + ((e + 1) * ENV_BYTES + lane_off));
-        const uint32_t P = __builtin_amdgcn_readlane(Pv, k);
-        uint32_t R = 0;
-        if (!(P & PB_RUNNING)) {
-            // ---- rare: finished environment
-            if (a.hot_flags & WF_HOT_AUTO_RESET) {
-                EnvS s = { 0, 0, 0, (uint32_t)__builtin_amdgcn_readlane(episode, k), 0 };
-                const WfCold *cold = a.cold;
-                uint32_t e_pin = e;
-                asm volatile("" : "+s"(cold), "+s"(e_pin));
-                cold_ptr cc = (cold_ptr)(uintptr_t)cold;
-                uint32_t t[4], u[4], h[4];
-                reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s);
-                const uint32_t qs = s.ay * W + s.ax;
-                uint32_t r[4];
+    // The whole loop runs with EXEC = the lanes that own cells: idle lanes never load,
+    // store, or contribute ballot bits, so no validity masks are needed anywhere.
+    // geo bit j of a lane = its cell j is a border cell (per-lane constant instead of
+    // 64-bit scalar constants).
+    uint32_t bgeo = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | ((lane == (qs >> 2) && (qs & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
-                if (active) *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(r[0], r[1], r[2], r[3]);
-                ax = (lane == k ? (s.ax) : ax);
-                ay = (lane == k ? (s.ay) : ay);
-                fl = (lane == k ? (s.fl) : fl);
-                episode = (lane == k ? (s.episode) : episode);
-                tick = (lane == k ? (s.tick) : tick);
-                R = RB_WASRESET;
-            }
-            Rv = (lane == k ? (R) : Rv);
-            continue;
-        }
-        uint32_t c[4] = { raw.x, raw.y, raw.z, raw.w };     // packed cells: type | fuel<<8 | heat<<16 | agent<<24
-        u64 FIRE[4];                                        // fire cells after the tick
-        if (do_update) {
-            // ---- ForestFire.update (forest_fire.py:85-106)
-            u64 STILL[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // reduce_fuel (environment.py:297-307)
-                const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
-                STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
-                c[j] += lanebit(F) ? K_FIRE_STEP : 0u;                         // fuel -= 1, fire -> burnt ...
-            }
-            u64 border_hit = 0;
-            static_for<4>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                using C = CM<W, H, j>;
-                c[j] -= lanebit(STILL[j]) ? 1u : 0u;                           // ... unless still burning
-                // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294), branch-free so
-                // that every mask stays a wave-uniform scalar
-                const u64 GR = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
-                const uint32_t cnt = (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
-                                     (lanebit(nb_lf<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_rt<W, H, j>(STILL)) ? 1u : 0u);
-                const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
-                const u64 IGN = GR & __ballot(cnt >= room);
-                const uint32_t cn = c[j] + (min(cnt, room) << 16) + (lanebit(IGN) ? 1u : 0u);   // heat saturates; grass -> fire
-                c[j] = lanebit(GR) ? cn : c[j];
-                border_hit |= IGN & C::BORDER;                                 // set_fire_to :245-246
-                FIRE[j] = STILL[j] | IGN;
-            });
-            R |= border_hit ? RB_BORDER : 0u;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
-        }
-        const bool anyfire = (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) != 0;
-        R |= anyfire ? RB_ANYFIRE : 0u;
-        // ---- containment part of World.get_reward (environment.py:345-377)
-        if ((P & PB_PRECHECK) && anyfire && !(R & RB_BORDER)) {
-            typedef u64 u64x4 __attribute__((ext_vector_type(4)));
-            typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
-            u64 RB[4];
-            if ((P & PB_VALID) && !(P & PB_RING)) {
-                const u64x4 rbv = *(const_u64x4_ptr)(uintptr_t)(a.reach + (size_t)e * 4);
-                RB[0] = rbv.x; RB[1] = rbv.y; RB[2] = rbv.z; RB[3] = rbv.w;
-            } else {
-                u64 PASS[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) PASS[j] = ~__ballot((c[j] & 0xffu) >= (uint32_t)WF_DIRT);
-                static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
-                flood<W, H>(RB, PASS);
-                if (lane == 0) {
-                    ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(a.reach + (size_t)e * 4);
-                    rp[0] = make_ulonglong2(RB[0], RB[1]);
-                    rp[1] = make_ulonglong2(RB[2], RB[3]);
-                }
-                R |= RB_RECOMPUTED;
-            }
-            // stale RB bits on cells dug since the last flood are harmless: fire never sits there
-            if (!((FIRE[0] & RB[0]) | (FIRE[1] & RB[1]) | (FIRE[2] & RB[2]) | (FIRE[3] & RB[3]))) R |= RB_CONTAINED;
-        }
-        if (!anyfire) {                                                        // :384-387 burnt out (rare)
-            uint32_t healthy = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) healthy += (uint32_t)__popcll(__ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS));
-            R |= healthy << RB_HEALTHY_SHIFT;
-        }
-        if (active) *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(c[0], c[1], c[2], c[3]);
-        Rv = (lane == k ? (R) : Rv);
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t q = 4u * lane + (uint32_t)j, x = q % W, y = q / W;
+        const uint32_t inner = ((x - 1u) | (y - 1u) | ((uint32_t)(W - 2) - x) | ((uint32_t)(H - 2) - y)) >> 31;
+        bgeo |= inner << j;
     }
+    asm volatile("" : "+v"(bgeo));
+    const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
+    if (active) {
+        uint4 raw_next = *reinterpret_cast<const uint4 *>(planes_b + (e0 * ENV_BYTES + lane_off));
+        for (uint32_t k = 0; k < ng; ++k) {
+            const uint32_t e = e0 + k;
+            const uint4 raw = raw_next;
+            {   // prefetch the next environment of the group (clamped: the last one re-reads itself)
+                const uint32_t en = e0 + min(k + 1u, ng - 1u);
+                raw_next = *reinterpret_cast<const uint4 *>(planes_b + (en * ENV_BYTES + lane_off));
+            }
+            const uint32_t P = __builtin_amdgcn_readlane(Pv, k);
+            uint32_t R = 0;
+            if (!(P & PB_RUNNING)) {
+                // ---- rare: finished environment
+                if (a.hot_flags & WF_HOT_AUTO_RESET) {
+                    EnvS s = { 0, 0, 0, (uint32_t)__builtin_amdgcn_readlane(episode, k), 0 };
+                    const WfCold *cold = a.cold;
+                    uint32_t e_pin = e;
+                    asm volatile("" : "+s"(cold), "+s"(e_pin));
+                    cold_ptr cc = (cold_ptr)(uintptr_t)cold;
+                    uint32_t t[4], u[4], h[4];
+                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s);
+                    const uint32_t qs = s.ay * W + s.ax;
+                    uint32_t r[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | ((lane == (qs >> 2) && (qs & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
+                    *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(r[0], r[1], r[2], r[3]);
+                    ax = (lane == k ? s.ax : ax);
+                    ay = (lane == k ? s.ay : ay);
+                    fl = (lane == k ? s.fl : fl);
+                    episode = (lane == k ? s.episode : episode);
+                    tick = (lane == k ? s.tick : tick);
+                    R = RB_WASRESET;
+                }
+                Rv = (lane == k ? R : Rv);
+                continue;
+            }
+            uint32_t c[4] = { raw.x, raw.y, raw.z, raw.w };     // packed cells: type | fuel<<8 | heat<<16 | agent<<24
+            u64 FIRE[4];                                        // fire cells after the tick
+            if (do_update) {
+                // ---- ForestFire.update (forest_fire.py:85-106)
+                u64 STILL[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // reduce_fuel (environment.py:297-307)
+                    const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+                    STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
+                    c[j] += lanebit(F) ? K_FIRE_STEP : 0u;                         // fuel -= 1, fire -> burnt ...
+                }
+                uint32_t ign_bits = 0;
+                static_for<4>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    using C = CM<W, H, j>;
+                    c[j] -= lanebit(STILL[j]) ? 1u : 0u;                           // ... unless still burning
+                    // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294), branch-free so
+                    // that every mask stays a wave-uniform scalar.  Row wrap: compile-time lane masks.
+                    const u64 GR = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
+                    u64 LF = j > 0 ? STILL[(j + 3) & 3] : (STILL[3] << 1);
+                    u64 RT = j < 3 ? STILL[(j + 1) & 3] : (STILL[0] >> 1);
+                    if (C::NOT_X0 != C::VALID) LF &= C::NOT_X0;
+                    if (C::NOT_XL != C::VALID) RT &= C::NOT_XL;
+                    const uint32_t cnt = (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
+                                         (lanebit(LF) ? 1u : 0u) + (lanebit(RT) ? 1u : 0u);
+                    const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
+                    const u64 IGN = GR & __ballot(cnt >= room);
+                    const uint32_t ig = lanebit(IGN) ? 1u : 0u;
+                    const uint32_t cn = c[j] + (min(cnt, room) << 16) + ig;        // heat saturates; grass -> fire
+                    c[j] = lanebit(GR) ? cn : c[j];
+                    ign_bits |= ig << j;
+                    FIRE[j] = STILL[j] | IGN;
+                });
+                // set_fire_to :245-246: a newly ignited border cell
+                R |= __ballot((ign_bits & bgeo) != 0u) ? RB_BORDER : 0u;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+            }
+            const bool anyfire = (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) != 0;
+            R |= anyfire ? RB_ANYFIRE : 0u;
+            // ---- containment part of World.get_reward (environment.py:345-377)
+            if ((P & PB_PRECHECK) && anyfire && !(R & RB_BORDER)) {
+                typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+                typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
+                u64 RB[4];
+                if ((P & PB_VALID) && !(P & PB_RING)) {
+                    const u64x4 rbv = *(const_u64x4_ptr)(uintptr_t)(a.reach + (size_t)e * 4);
+                    RB[0] = rbv.x; RB[1] = rbv.y; RB[2] = rbv.z; RB[3] = rbv.w;
+                } else {
+                    u64 PASS[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
+                    static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
+                    flood<W, H>(RB, PASS);
+                    if (lane == 0) {
+                        ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(a.reach + (size_t)e * 4);
+                        rp[0] = make_ulonglong2(RB[0], RB[1]);
+                        rp[1] = make_ulonglong2(RB[2], RB[3]);
+                    }
+                    R |= RB_RECOMPUTED;
+                }
+                // stale RB bits on cells dug since the last flood are harmless: fire never sits there
+                if (!((FIRE[0] & RB[0]) | (FIRE[1] & RB[1]) | (FIRE[2] & RB[2]) | (FIRE[3] & RB[3]))) R |= RB_CONTAINED;
+            }
+            if (!anyfire) {                                                        // :384-387 burnt out (rare)
+                uint32_t healthy = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) healthy += (uint32_t)__popcll(__ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS));
+                R |= healthy << RB_HEALTHY_SHIFT;
+            }
+            *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(c[0], c[1], c[2], c[3]);
+            Rv = (lane == k ? R : Rv);
+        }
+    }
+    // (the host caps G at the number of cell-owning lanes, so every env-lane k < ng took part above)
 
     // ================= phase C: lanes = environments =================
     {
@@ -833,8 +855,10 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
         // single step: group layout.  G environments per wave, sized so that every resident wave
         // slot of the chip (32 per CU) gets one group.
         WfArgs g = a;
-        int G = 1;
-        while (G < 64 && (long long)G * num_cus * 32 < a.batch) G *= 2;
+        int G = 1, gmax = 1;
+        while (gmax * 2 <= (W * H) / 4 && gmax < 32) gmax *= 2;   // env-lane k must be a cell-owning lane
+        if (a.group > 0) gmax = a.group < gmax ? a.group : gmax;  // experiment override (WF_GROUP)
+        while (G < gmax && (long long)G * num_cus * 32 < a.batch) G *= 2;
         g.group = G;
         const int waves = (a.batch + G - 1) / G;
         hipLaunchKernelGGL((wf_step_group<W, H>), dim3((waves + 3) / 4), dim3(256), 0, s, g);
