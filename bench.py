@@ -85,6 +85,18 @@ def cpu_baseline(size, seed, seconds):
                       f"(reference Python path: 5.5e5 cell-updates/s on 1 core, BASELINE.md section 2)"}
 
 
+def measured_traffic(batch, size):
+    """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC
+    passes (profiles/traffic.json; bench.py cannot collect PMC counters on itself)."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        if t["algorithmic_bytes_per_launch"] == BYTES_PER_CELL_UPDATE * batch * size * size:
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -152,6 +164,19 @@ def main():
         fused = {"steps_per_launch": F, "launches": reps,
                  "cell_updates_per_s_per_gpu": cells * F * reps / (f_ms * 1e-3)}
 
+    # extra: the synchronous host-buffer entry point (numpy actions in, reward/done out): PCIe and
+    # host synchronisation included.  Reported for completeness; it is never `value`.
+    host_api = None
+    if world == 1:
+        a_np = make_actions(30, lo, lo + B, args.seed + 2)
+        env.step_many(a_np[0])
+        th = time.perf_counter()
+        for s in range(1, 30):
+            env.step_many(a_np[s])
+        th = time.perf_counter() - th
+        host_api = {"cell_updates_per_s": cells * 29 / th, "us_per_step": th / 29 * 1e6,
+                    "note": "wf_step(): H2D actions + launch + D2H reward/done + stream sync per step"}
+
     t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,13 +207,15 @@ def main():
                        "kernel": env.kernel_name},
             "env_steps_per_s": value / (S * S),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "wf_step_wave", "launch_us": launch_ms * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, S),
+                         "kernel": f"wf_step_group<{S},{S}>", "launch_us": launch_ms * 1e3,
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells},
             "done_frac_last_step": done_frac,
         }
         if fused:
             out["fused"] = fused
+        if host_api:
+            out["host_buffer_api"] = host_api
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.seed, args.cpu_seconds)
         print(json.dumps(out), flush=True)

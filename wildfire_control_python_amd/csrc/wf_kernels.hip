@@ -857,8 +857,8 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
         WfArgs g = a;
         int G = 1, gmax = 1;
         while (gmax * 2 <= (W * H) / 4 && gmax < 32) gmax *= 2;   // env-lane k must be a cell-owning lane
-        if (a.group > 0) gmax = a.group < gmax ? a.group : gmax;  // experiment override (WF_GROUP)
         while (G < gmax && (long long)G * num_cus * 32 < a.batch) G *= 2;
+        if (a.group > 0) G = a.group < gmax ? a.group : gmax;     // experiment override (WF_GROUP)
         g.group = G;
         const int waves = (a.batch + G - 1) / G;
         hipLaunchKernelGGL((wf_step_group<W, H>), dim3((waves + 3) / 4), dim3(256), 0, s, g);
@@ -889,7 +889,7 @@ WfFamily wf_pick_family(int H, int W)
 const char *wf_family_name(WfFamily f, int, int)
 {
     switch (f) {
-    case WF_FAM_WAVE: return "wf_step_wave (one env per wavefront, ballot bitboards)";
+    case WF_FAM_WAVE: return "wf_step_group/wf_step_wave (wave-per-env CA core on ballot bitboards; env logic lane-parallel)";
     case WF_FAM_TILED: return "wf_step_tiled (row strips, LDS halo masks)";
     default: return "none";
     }
