@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--ignite-ppm", type=int, default=0, help="extra pre-ignited cells per million at reset (config 4)")
+    ap.add_argument("--noop", action="store_true", help="no agent actions (configs 2 and 4)")
     return ap.parse_args()
 
 
@@ -117,12 +119,15 @@ def main():
     S, B, K, Wm = args.size, args.batch, args.steps, args.warmup
     cells = B * S * S
     env = make_shard(B * world, S, rank=rank, world_size=world, device=local, seed=args.seed,
-                     auto_reset=True, fuel_range=(10, 40), containment=True)
+                     auto_reset=True, fuel_range=(10, 40), containment=None, ignite_ppm=args.ignite_ppm)
     lo = rank * B
     env.reset(seed=args.seed)
     total = Wm + K
     dev = torch.device("cuda", local)
-    d_act = torch.from_numpy(make_actions(total, lo, lo + B, args.seed)).to(dev)
+    acts = make_actions(total, lo, lo + B, args.seed)
+    if args.noop:
+        acts[:] = 5
+    d_act = torch.from_numpy(acts).to(dev)
     d_rew = torch.empty((1, B), dtype=torch.float64, device=dev)
     d_done = torch.empty((1, B), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -200,7 +205,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": f"{B} batched {S}x{S} grids per GPU, random fuel U{{10..40}}, "
-                                   "uniform N/S/E/W dig-action injected each step, containment test on, "
+                                   + ("no-op actions, " if args.noop else "uniform N/S/E/W dig-action injected each step, ")
+                                   + ("containment test on, " if env.containment else "containment test off, ") +
                                    "device auto-reset of finished envs (BASELINE configs[2])",
                        "global_batch": B * world, "grid": [S, S], "ticks_per_launch": 1,
                        "parallelism": f"env-shard x{world}, no collective",
@@ -208,7 +214,8 @@ def main():
             "env_steps_per_s": value / (S * S),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, S),
-                         "kernel": f"wf_step_group<{S},{S}>", "launch_us": launch_ms * 1e3,
+                         "kernel": (f"wf_step_group<{S},{S}>" if "group" in env.kernel_name else env.kernel_name.split(" ")[0]),
+                         "launch_us": launch_ms * 1e3,
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells},
             "done_frac_last_step": done_frac,
         }

@@ -81,6 +81,49 @@ def test_step_matches_oracle_random_actions(wf, W, H):
     env.close()
 
 
+# big-grid families: row-strip tiles with LDS halo masks (W % 4 == 0, W <= 256) and the generic
+# thread-per-cell kernel (any other shape).  No containment test there yet -> oracle containment off.
+BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70, 6), (256, 256, 3),
+              (11, 11, 128), (13, 10, 128), (30, 23, 48), (260, 9, 8)]
+
+
+@pytest.mark.parametrize("W,H,B", BIG_SHAPES)
+def test_big_grid_step_matches_oracle(wf, W, H, B):
+    T = 70
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
+                               auto_reset=(W == 24))
+    assert not env.containment and ("tiled" in env.kernel_name or "cells" in env.kernel_name)
+    env.reset(seed=123)
+    op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=0)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=123, params=op)
+    gp, ge = env.download()
+    np.testing.assert_array_equal(gp, planes, err_msg="reset planes")
+    np.testing.assert_array_equal(_envs(ge), envs, err_msg="reset envs")
+    rng = np.random.default_rng(W * 1000 + H)
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        obs, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op)
+        if W == 24 and stopped.any():      # auto-reset shape
+            O.reset(planes, envs, seed=5, mask=stopped, params=op)
+            ro[stopped], do[stopped] = 0.0, 0
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        if t % 10 == 0:
+            np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+    env.close()
+
+
+def test_big_grid_containment_is_refused_not_ignored(wf):
+    with pytest.raises(Exception):
+        wf.BatchedForestFire(4, size=64, containment=True)
+
+
 def test_fused_steps_equal_single_steps(wf):
     B, T = 256, 48
     a = np.random.default_rng(3).integers(0, 5, size=(T, B)).astype(np.int8)

@@ -35,7 +35,7 @@ def encode_action(a):
 class BatchedForestFire:
     def __init__(self, batch, size=None, *, width=None, height=None, device=0, metadata=None,
                  seed=0, env_id0=0, auto_reset=False, fuel_range=None, ignite_ppm=0,
-                 containment=True):
+                 containment=None):
         self.METADATA = dict(_DEFAULT_METADATA)
         if metadata:
             self.METADATA.update(metadata)
@@ -67,7 +67,8 @@ class BatchedForestFire:
         p = N.default_params()
         p.ignite_count = ignite_count(self.wind_speed)
         p.allow_dig_toggle = int(bool(self.METADATA["allow_dig_toggle"]))
-        p.containment = int(bool(containment))
+        # containment test of get_reward: built for the one-wave grid family; None = "if available"
+        p.containment = 1 if containment is None else int(bool(containment))
         p.auto_reset = int(bool(auto_reset))
         p.death_penalty = float(self.METADATA["death_penalty"])
         p.contained_bonus = float(self.METADATA["contained_bonus"])
@@ -83,6 +84,11 @@ class BatchedForestFire:
         h = ctypes.c_void_p()
         rc = self._lib.wf_create(ctypes.byref(h), self.device, self.batch, self.height,
                                  self.width, ctypes.byref(p))
+        if rc == -2 and containment is None:      # WF_ERR_UNSUPPORTED: big-grid family, no containment yet
+            p.containment = 0
+            rc = self._lib.wf_create(ctypes.byref(h), self.device, self.batch, self.height,
+                                     self.width, ctypes.byref(p))
+        self.containment = bool(p.containment)
         if rc != N.WF_OK:
             raise N.WildfireError(rc, f"wf_create(batch={batch}, H={self.height}, W={self.width})")
         self._h = h

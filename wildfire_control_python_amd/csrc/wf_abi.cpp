@@ -31,6 +31,8 @@ struct wf_ctx {
     uint8_t *d_mask = nullptr;
     int8_t *d_obs = nullptr;
     WfCold *d_cold = nullptr;         // device copy of {params, spawn table} for the kernels' rare paths
+    uint8_t *d_mode = nullptr;        // big-grid families: per-env mode of the current step
+    uint32_t *d_acc = nullptr;        // big-grid families: per-env reduction words
     int staged_steps = 0;
     WfSpawn spawn;
     int last_hip = 0;
@@ -189,6 +191,9 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
     // the wave kernels address the planes with 32-bit byte offsets
     if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;
+    // the containment test (get_reward's A* part) is only built for the wave family so far
+    if (fam != WF_FAM_WAVE && pp.containment) return WF_ERR_UNSUPPORTED;
+    if (fam != WF_FAM_WAVE && (unsigned long long)H * W > 0xFFFFull * 0xFFFFull) return WF_ERR_UNSUPPORTED;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return WF_ERR_NO_DEVICE;
@@ -217,7 +222,13 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         if ((e = hipEventCreate(&c->ev1)) != hipSuccess) break;
         const size_t cells = (size_t)batch * H * W;
         if ((e = hipMalloc((void **)&c->planes, cells * 4)) != hipSuccess) break;
-        if (fam == WF_FAM_TILED && (e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
+        if (fam != WF_FAM_WAVE) {
+            if ((e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
+            if ((e = hipMalloc((void **)&c->d_mode, (size_t)batch)) != hipSuccess) break;
+            if ((e = hipMalloc((void **)&c->d_acc, (size_t)batch * 8)) != hipSuccess) break;
+            if ((e = hipMemsetAsync(c->d_mode, 0, (size_t)batch, c->stream)) != hipSuccess) break;
+            if ((e = hipMemsetAsync(c->d_acc, 0, (size_t)batch * 8, c->stream)) != hipSuccess) break;
+        }
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->reach, (size_t)batch * 4 * sizeof(u64))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_mask, (size_t)batch)) != hipSuccess) break;
@@ -246,7 +257,7 @@ int wf_destroy(wf_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_actions, c->d_reward,
-                     c->d_done, c->d_mask, c->d_obs, c->d_cold };
+                     c->d_done, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc };
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -259,6 +270,7 @@ int wf_destroy(wf_ctx *c)
 int wf_set_params(wf_ctx *c, const wf_params *p)
 {
     if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
+    if (c->fam != WF_FAM_WAVE && p->containment) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->p = *p;
@@ -306,7 +318,8 @@ int wf_reset_device(wf_ctx *c, const uint8_t *d_mask, uint64_t seed)
     WfArgs a = base_args(c);
     a.mask = d_mask;
     a.reset_seed = seed;
-    HIP_TRY(c, wf_launch_reset(c->fam, a, c->stream, c->num_cus));
+    if (c->fam == WF_FAM_WAVE) HIP_TRY(c, wf_launch_reset(c->fam, a, c->stream, c->num_cus));
+    else HIP_TRY(c, wf_launch_reset_big(a, d_mask, -1, seed, c->stream));
     return WF_OK;
 }
 
@@ -326,15 +339,27 @@ int wf_step_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t upd
 {
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    WfArgs a = base_args(c);
-    a.actions = d_actions;
-    a.reward = d_reward;
-    a.done = d_done;
-    a.n_steps = n_steps;
-    a.update_mask = update_mask;
-    HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
-    if (c->fam == WF_FAM_TILED) {   // ping-pong: the freshly written buffer becomes current
-        uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t;
+    if (c->fam == WF_FAM_WAVE) {
+        WfArgs a = base_args(c);
+        a.actions = d_actions;
+        a.reward = d_reward;
+        a.done = d_done;
+        a.n_steps = n_steps;
+        a.update_mask = update_mask;
+        HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
+        return WF_OK;
+    }
+    // big-grid families: one launch sequence per step, source planes -> destination planes
+    for (int st = 0; st < n_steps; ++st) {
+        WfArgs a = base_args(c);
+        const size_t off = (size_t)st * (size_t)c->batch;
+        a.actions = d_actions ? d_actions + off : nullptr;
+        a.reward = d_reward ? d_reward + off : nullptr;
+        a.done = d_done ? d_done + off : nullptr;
+        a.n_steps = 1;
+        a.update_mask = (update_mask >> st) & 1ull;
+        HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode, c->d_acc, c->p.seed, c->stream));
+        uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t;   // ping-pong
     }
     return WF_OK;
 }

@@ -1,0 +1,49 @@
+// wf_device.h - device helpers shared by the kernel files (wf_kernels.hip, wf_tiled.hip).
+#pragma once
+#include "wf_internal.h"
+
+namespace wfdev {
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool lanebit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// ----------------------------------------------------------------------------
+// counter-based stream (same arithmetic as oracle/wf_oracle.c, written independently)
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t below(uint32_t r, uint32_t n) { return __umulhi(r, n); }
+
+struct EnvKey {
+    uint32_t k0, k1;
+    __device__ __forceinline__ EnvKey(u64 seed, u64 env_id, uint32_t episode)
+    {
+        u64 k = mix64(mix64(seed ^ (env_id * 0x9E3779B97F4A7C15ull)) + (u64)episode);
+        k0 = (uint32_t)k;
+        k1 = (uint32_t)(k >> 32);
+    }
+    __device__ __forceinline__ uint32_t draw(uint32_t d) const { return hash32(k0 ^ hash32(d + k1)); }
+};
+
+// move table, 6 bits per action 0..4: (dx+1) | (dy+1)<<2 | is_move<<4; entry 4 = "no move"
+// (N=(0,-1) S=(0,+1) E=(+1,0) W=(-1,0): environment.py:163-171)
+constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 | (2u | 1u << 2 | 16u) << 12 |
+                              (0u | 1u << 2 | 16u) << 18 | (1u | 1u << 2) << 24;
+
+typedef const WfCold __attribute__((address_space(4))) *cold_ptr;
+
+}  // namespace wfdev

@@ -49,7 +49,7 @@ struct WfArgs {
 };
 
 // kernel families (wf_kernels.hip)
-enum WfFamily { WF_FAM_NONE = 0, WF_FAM_WAVE = 1, WF_FAM_TILED = 2 };
+enum WfFamily { WF_FAM_NONE = 0, WF_FAM_WAVE = 1, WF_FAM_TILED = 2, WF_FAM_CELLS = 3 };
 
 // Returns the family able to serve (H, W), and its name.
 WfFamily wf_pick_family(int H, int W);
@@ -58,6 +58,10 @@ const char *wf_family_name(WfFamily f, int H, int W);
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
+// big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 auto_seed, hipStream_t s);
+// sel == nullptr: all envs; sel_value >= 0: envs with sel[e] == sel_value; sel_value < 0: envs with sel[e] != 0
+hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s);
 hipError_t wf_launch_invalidate_reach(wf_env *envs, int batch, hipStream_t s);
 hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, int H, int W,
                                hipStream_t s);

@@ -33,9 +33,11 @@
 // No MFMA anywhere: the path is HBM-bound byte work, not a contraction.
 #include <utility>
 
-#include "wf_internal.h"
+#include "wf_device.h"
 
 namespace {
+
+using namespace wfdev;
 
 // ----------------------------------------------------------------------------
 // compile-time geometry of the wave layout
@@ -80,9 +82,6 @@ __device__ __forceinline__ void static_for(F &&f)
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ bool lanebit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
-
 // Neighbour masks of a per-component cell set S (bit l of S[j] <-> cell 4l+j).
 template <int W, int H, int J>
 __device__ __forceinline__ u64 nb_up(const u64 (&S)[4]) { return S[CM<W, H, J>::UP_SRC] << CM<W, H, J>::UP_SH; }
@@ -99,43 +98,10 @@ __device__ __forceinline__ u64 nb_rt(const u64 (&S)[4])
     return (J < 3 ? S[(J + 1) & 3] : (S[0] >> 1)) & CM<W, H, J>::NOT_XL;
 }
 
-// ----------------------------------------------------------------------------
-// counter-based stream (same arithmetic as oracle/wf_oracle.c, written independently)
-// ----------------------------------------------------------------------------
-__device__ __forceinline__ u64 mix64(u64 z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint32_t hash32(uint32_t x)
-{
-    x ^= x >> 16;
-    x *= 0x7FEB352Du;
-    x ^= x >> 15;
-    x *= 0x846CA68Bu;
-    x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ uint32_t below(uint32_t r, uint32_t n) { return __umulhi(r, n); }
-
-struct EnvKey {
-    uint32_t k0, k1;
-    __device__ __forceinline__ EnvKey(u64 seed, u64 env_id, uint32_t episode)
-    {
-        u64 k = mix64(mix64(seed ^ (env_id * 0x9E3779B97F4A7C15ull)) + (u64)episode);
-        k0 = (uint32_t)k;
-        k1 = (uint32_t)(k >> 32);
-    }
-    __device__ __forceinline__ uint32_t draw(uint32_t d) const { return hash32(k0 ^ hash32(d + k1)); }
-};
-
 struct EnvS {        // wave-uniform scalars of one environment
     uint32_t ax, ay, fl, episode, tick;
 };
 
-typedef const WfCold __attribute__((address_space(4))) *cold_ptr;
 
 // World.reset() into registers (environment.py:186-212, reset_map :59-67,
 // get_agent_location utility.py:66-78) with the counter-based stream.
@@ -214,11 +180,6 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 {
     return __builtin_amdgcn_ubfe(bperm(q & ~3u, tp), (q & 3u) << 3, 8u);
 }
-
-// move table, 6 bits per action 0..4: (dx+1) | (dy+1)<<2 | is_move<<4; entry 4 = "no move"
-// (N=(0,-1) S=(0,+1) E=(+1,0) W=(-1,0): environment.py:163-171)
-constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 | (2u | 1u << 2 | 16u) << 12 |
-                              (0u | 1u << 2 | 16u) << 18 | (1u | 1u << 2) << 24;
 
 // Containment shortcut: removing a cell q from the passable set can only change which
 // cells are connected to the border when q is itself a border cell, or when the
@@ -883,14 +844,16 @@ WfFamily wf_pick_family(int H, int W)
 #define X(w, h) if (W == w && H == h) return WF_FAM_WAVE;
     WF_WAVE_SHAPES(X)
 #undef X
-    return WF_FAM_NONE;
+    if (W >= 4 && W <= 256 && W % 4 == 0 && H >= 1) return WF_FAM_TILED;
+    return WF_FAM_CELLS;
 }
 
 const char *wf_family_name(WfFamily f, int, int)
 {
     switch (f) {
     case WF_FAM_WAVE: return "wf_step_group/wf_step_wave (wave-per-env CA core on ballot bitboards; env logic lane-parallel)";
-    case WF_FAM_TILED: return "wf_step_tiled (row strips, LDS halo masks)";
+    case WF_FAM_TILED: return "wf_step_tiled (16-row strips per wave, ballot row masks, LDS-staged strip halos)";
+    case WF_FAM_CELLS: return "wf_step_cells (generic thread-per-cell)";
     default: return "none";
     }
 }

@@ -1,0 +1,383 @@
+// wf_tiled.hip - gfx950 kernels for grids that do not fit one wavefront (e.g. 256x256).
+//
+// Same rule as wf_kernels.hip (synchronous integer restatement of
+// Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step is
+//   wf_big_pre   lanes = environments: Agent.move / toggle / death (environment.py:116-171);
+//                the dug cell and the agent_pos bytes are written straight into the grid
+//   wf_step_tiled (W % 4 == 0, W <= 256)  or  wf_step_cells (any shape)
+//                the CA tick, source planes -> destination planes (ping-pong), per-env
+//                reductions (any fire left, fire at border, healthy cells) by atomics
+//   wf_big_post  lanes = environments: World.RUNNING, reward, done, records
+//
+// wf_step_tiled: a workgroup = 4 waves = 4 vertically adjacent strips of TR rows of one
+// environment.  A wave sweeps its strip top to bottom; lane l owns cells x = 4l..4l+3 of
+// the current row (one coalesced dwordx4 per lane, a 256-wide row = one 1 KiB wave load).
+// "Still burning" becomes four 64-bit lane masks per row (wavefront ballot).  The vertical
+// neighbours of a cell are THE SAME BIT of the masks of the rows above and below, the
+// horizontal ones are the adjacent component / a one-lane shift, so a row needs the masks
+// of three rows and no per-cell index arithmetic.  The masks of each strip's first and
+// last row are staged in LDS so that the strips of a workgroup hand their halo to the
+// neighbour strip without touching memory again; only the workgroup's outer halo rows
+// are read from global memory.
+#include "wf_device.h"
+
+namespace {
+
+using namespace wfdev;
+
+enum { MODE_COPY = 0, MODE_STEP = 1, MODE_RESET = 2 };
+constexpr int TR = 16;   // rows per wave strip
+
+// ---------------------------------------------------------------------------- pre
+__global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (uint32_t)a.batch) return;
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H;
+    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu;
+    if (!(fl & WF_F_RUNNING)) {
+        const bool rs = (a.hot_flags & WF_HOT_AUTO_RESET) != 0;
+        mode[e] = rs ? MODE_RESET : MODE_COPY;     // frozen: the reference is never stepped after done
+        if (a.reward) a.reward[e] = 0.0;
+        if (a.done) a.done[e] = rs ? 0 : 1;
+        return;
+    }
+    mode[e] = MODE_STEP;
+    const uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[e] : 0xffu;
+    uint8_t *pe = reinterpret_cast<uint8_t *>(a.planes) + (size_t)e * H * W * 4;
+    // ---- Agent.move (environment.py:141-155)
+    const uint32_t ent = MOVE_LUT >> (min(act, 4u) * 6u);
+    const uint32_t ism = (ent >> 4) & 1u;
+    const uint32_t nx = ax + (ent & 3u) - 1u, ny = ay + ((ent >> 2) & 3u) - 1u;      // :163-171
+    const uint32_t out = ((W - 1u - nx) | nx | (H - 1u - ny) | ny) >> 31;
+    const uint32_t inb = ism & (out ^ 1u);                                            // :146 inbounds
+    const uint32_t qa = ay * W + ax;
+    uint32_t qd = inb ? ny * W + nx : qa;
+    const uint32_t td = pe[(size_t)qd * 4], tcur = pe[(size_t)qa * 4];
+    const uint32_t moved = inb & (td != WF_WATER ? 1u : 0u);                          // :146 traversable
+    const uint32_t dfire = moved & (td == WF_FIRE ? 1u : 0u);
+    uint32_t dug = moved & ((fl >> 2) & 1u) & ((td == WF_GRASS || td == WF_BURNT) ? 1u : 0u);   // :151-152, :125-133
+    const uint32_t vis_before = (fl >> 1) & 1u;
+    fl = (fl & ~(ism << 1)) | (moved << 1) | (dfire << 3);                            // :142, :148-149, :154-155
+    if (moved) { ax = nx; ay = ny; }
+    uint32_t ta = moved ? td : tcur;
+    if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && act == 4u) {                              // forest_fire.py:35-36
+        fl ^= WF_F_DIGGING;
+        // divergence (documented): a burning cell is left burning (see wf_kernels.hip)
+        dug = ((fl >> 2) & 1u) & ((tcur == WF_GRASS || tcur == WF_BURNT) ? 1u : 0u);
+        qd = qa;
+    }
+    if (dug) ta = WF_DIRT;
+    if (a.update_mask & 1ull) {                                                        // forest_fire.py:87
+        const uint32_t dies = (fl & 1u) & (((fl >> 3) & 1u) | (ta == WF_FIRE ? 1u : 0u));
+        if (dies) fl &= ~(uint32_t)(WF_F_ALIVE | WF_F_VISIBLE);
+    }
+    if (vis_before) pe[(size_t)qa * 4 + 3] = 0;
+    if (dug) pe[(size_t)qd * 4] = (uint8_t)WF_DIRT;
+    if (fl & WF_F_VISIBLE) pe[(size_t)(ay * W + ax) * 4 + 3] = 1;
+    ev.x = ax | (ay << 16);
+    ev.y = fl;
+    *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+}
+
+// ---------------------------------------------------------------------------- post
+__global__ __launch_bounds__(256) void wf_big_post(const WfArgs a, const uint8_t *mode, uint32_t *acc)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (uint32_t)a.batch) return;
+    const uint32_t A = acc[2 * e], healthy = acc[2 * e + 1];
+    acc[2 * e] = 0;
+    acc[2 * e + 1] = 0;
+    if (mode[e] != MODE_STEP) return;
+    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    uint32_t fl = ev.y & 0xffffu;
+    const uint32_t anyfire = A & 1u, bhit = (A >> 1) & 1u;
+    const uint32_t upd = (a.update_mask & 1ull) ? 1u : 0u;
+    fl |= bhit << 5;                                                                   // set_fire_to :245-246
+    if (upd && (!(fl & WF_F_ALIVE) || !anyfire)) fl &= ~(uint32_t)WF_F_RUNNING;        // forest_fire.py:105-106
+    ev.w += upd;
+    double reward = a.default_reward;                                                  // environment.py:390
+    if (!anyfire) reward = a.contained_bonus * ((double)healthy / (double)((uint32_t)a.H * (uint32_t)a.W));   // :384-387
+    if (!(fl & WF_F_ALIVE)) reward = a.death_penalty;                                  // :380-381
+    ev.y = fl;
+    *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+    if (a.reward) a.reward[e] = reward;
+    if (a.done) a.done[e] = (fl & WF_F_RUNNING) ? 0 : 1;                               // forest_fire.py:48
+}
+
+// ---------------------------------------------------------------------------- tiled step
+struct RowMasks { u64 m[4]; };
+
+__device__ __forceinline__ void still_masks(const uint4 &r, u64 (&S)[4])
+{
+    const uint32_t c[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // reduce_fuel (environment.py:297-307): fire cell with fuel-1 > 0
+        S[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);
+}
+
+__global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc)
+{
+    __shared__ u64 halo[4][2][4];                    // [strip][first,last row][component]
+    const uint32_t lane = __lane_id();
+    const uint32_t wv = rfl(threadIdx.x >> 6);
+    const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
+    const uint32_t gx = (H + 4u * TR - 1u) / (4u * TR);          // workgroups per environment
+    const uint32_t e = blockIdx.x / gx;
+    const uint32_t r0 = ((blockIdx.x % gx) * 4u + wv) * TR;
+    const uint32_t r1 = min(r0 + TR, H);
+    const bool has_rows = r0 < H;
+    const bool active = lane < LW;
+    const uint32_t ign = (uint32_t)a.ignite_count;
+    const bool step = (mode[e] == MODE_STEP) && (a.update_mask & 1ull);
+    const bool reduce = mode[e] == MODE_STEP;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+    uint4 *dst = reinterpret_cast<uint4 *>(a.planes_out) + (size_t)e * H * LW + lane;
+    const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+
+    // ---- prologue: masks of the strip's first and last row -> LDS
+    uint4 first = inert, last = inert;
+    u64 Sf[4] = { 0, 0, 0, 0 }, Sl[4] = { 0, 0, 0, 0 };
+    if (has_rows) {
+        if (active) {
+            first = src[(size_t)r0 * LW];
+            last = src[(size_t)(r1 - 1) * LW];
+        }
+        still_masks(first, Sf);
+        still_masks(last, Sl);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { halo[wv][0][j] = Sf[j]; halo[wv][1][j] = Sl[j]; }
+    }
+    __syncthreads();
+    if (!has_rows) return;
+
+    // masks of the row above the strip / below the strip (original state)
+    u64 Sp[4] = { 0, 0, 0, 0 }, Sb[4] = { 0, 0, 0, 0 };
+    if (r0 > 0) {
+        if (wv > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 v = halo[wv - 1][1][j];
+                Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+            }
+        } else {   // workgroup's outer halo: from global memory
+            uint4 up = inert;
+            if (active) up = src[(size_t)(r0 - 1) * LW];
+            still_masks(up, Sp);
+        }
+    }
+    if (r1 < H) {
+        if (wv < 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 v = halo[wv + 1][0][j];
+                Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+            }
+        } else {
+            uint4 dn = inert;
+            if (active) dn = src[(size_t)r1 * LW];
+            still_masks(dn, Sb);
+        }
+    }
+
+    // ---- sweep
+    uint32_t anyfire = 0, bhit = 0, healthy = 0;
+    uint4 cur = first, nxt = inert;
+    u64 Sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Sc[j] = Sf[j];
+    if (r0 + 1 < r1 && active) nxt = src[(size_t)(r0 + 1) * LW];
+    for (uint32_t r = r0; r < r1; ++r) {
+        uint4 nn = inert;                                        // prefetch row r+2
+        if (r + 2 < r1 && active) nn = src[(size_t)(r + 2) * LW];
+        u64 Sn[4];
+        if (r + 1 < r1) still_masks(nxt, Sn);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Sn[j] = Sb[j];
+        }
+        uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
+        u64 FIRE[4], GR[4];
+        if (step) {
+            const bool edge_row = (r == 0) || (r == H - 1);
+            u64 border_hit = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+                c[j] += lanebit(F) ? 0xFFFFFF01u : 0u;                         // fuel -= 1, fire -> burnt ...
+                c[j] -= lanebit(Sc[j]) ? 1u : 0u;                              // ... unless still burning
+                const u64 G = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);   // idle lanes hold inert (dirt) cells
+                // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows
+                const u64 LF = j > 0 ? Sc[(j + 3) & 3] : (Sc[3] << 1);
+                const u64 RT = j < 3 ? Sc[(j + 1) & 3] : (Sc[0] >> 1);
+                const uint32_t cnt = (lanebit(Sp[j]) ? 1u : 0u) + (lanebit(Sn[j]) ? 1u : 0u) +
+                                     (lanebit(LF) ? 1u : 0u) + (lanebit(RT) ? 1u : 0u);
+                const uint32_t room = ign - ((c[j] >> 16) & 0xffu);
+                const u64 IGN = G & __ballot(cnt >= room);                     // apply_heat_from_to :278-294
+                const uint32_t cn = c[j] + (min(cnt, room) << 16) + (lanebit(IGN) ? 1u : 0u);
+                c[j] = lanebit(G) ? cn : c[j];
+                // set_fire_to :245-246: border = first/last row, x == 0, x == W-1
+                const u64 bm = edge_row ? ~0ull : (j == 0 ? 1ull : (j == 3 ? (1ull << (LW - 1)) : 0ull));
+                border_hit |= IGN & bm;
+                FIRE[j] = Sc[j] | IGN;
+                GR[j] = G & ~IGN;
+            }
+            bhit |= border_hit ? 1u : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+                GR[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
+            }
+        }
+        if (reduce) {
+            anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
+            healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
+        }
+        if (active) dst[(size_t)r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Sp[j] = Sc[j]; Sc[j] = Sn[j]; }
+        cur = nxt;
+        nxt = nn;
+    }
+    if (reduce && lane == 0) {
+        const uint32_t A = anyfire | (bhit << 1);
+        if (A) atomicOr(&acc[2 * e], A);
+        if (healthy) atomicAdd(&acc[2 * e + 1], healthy);
+    }
+}
+
+// ---------------------------------------------------------------------------- generic step
+// Any grid shape: one thread per cell, neighbours read from the source planes.
+__global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8_t *mode, uint32_t *acc)
+{
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
+    const size_t total = (size_t)a.batch * cells;
+    const uint32_t ign = (uint32_t)a.ignite_count;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t e = (uint32_t)(i / cells), q = (uint32_t)(i % cells), x = q % W, y = q / W;
+        const uint32_t *se = a.planes + (size_t)e * cells;
+        uint32_t c = se[q];
+        const uint32_t m = mode[e];
+        if (m == MODE_STEP && (a.update_mask & 1ull)) {
+            auto still = [&](uint32_t v) -> uint32_t { return ((v & 0xffu) == WF_FIRE && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
+            const uint32_t t = c & 0xffu;
+            if (t == WF_FIRE) {
+                c = c + 0xFFFFFF01u - still(c);                                    // reduce_fuel :297-307
+            } else if (t == WF_GRASS) {
+                uint32_t cnt = 0;                                                  // get_neighbours :311-326
+                if (x > 0) cnt += still(se[q - 1]);
+                if (x + 1 < W) cnt += still(se[q + 1]);
+                if (y > 0) cnt += still(se[q - W]);
+                if (y + 1 < H) cnt += still(se[q + W]);
+                const uint32_t room = ign - ((c >> 16) & 0xffu);
+                const uint32_t ig = cnt >= room ? 1u : 0u;                         // apply_heat_from_to :278-294
+                c += (min(cnt, room) << 16) + ig;
+                if (ig && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) atomicOr(&acc[2 * e], 2u);
+            }
+        }
+        a.planes_out[(size_t)e * cells + q] = c;
+        if (m == MODE_STEP) {
+            const uint32_t t = c & 0xffu;
+            // wave-aggregated when the whole wave sits in one env (the common case)
+            const uint32_t e0 = rfl(e);
+            if (__ballot(e != e0) == 0) {
+                const u64 f = __ballot(t == WF_FIRE), g = __ballot(t == WF_GRASS);
+                if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) {
+                    if (f) atomicOr(&acc[2 * e], 1u);
+                    if (g) atomicAdd(&acc[2 * e + 1], (uint32_t)__popcll(g));
+                }
+            } else {
+                if (t == WF_FIRE) atomicOr(&acc[2 * e], 1u);
+                if (t == WF_GRASS) atomicAdd(&acc[2 * e + 1], 1u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- reset
+// World.reset() (environment.py:186-212) in two kernels: records, then cells.
+__global__ __launch_bounds__(256) void wf_big_reset_rec(const WfArgs a, const uint8_t *sel, int sel_value, u64 seed)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (uint32_t)a.batch) return;
+    if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) return;
+    const WfCold *cold = a.cold;
+    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    const EnvKey key(seed, cold->p.env_id0 + (u64)e, ev.z);
+    const uint32_t r = below(key.draw(0), 3u);
+    const uint32_t k = below(key.draw(1), (uint32_t)cold->spawn.n[r]);
+    const uint32_t sx = (uint32_t)a.W / 2u + (int)cold->spawn.dx[r][k], sy = (uint32_t)a.H / 2u + (int)cold->spawn.dy[r][k];
+    ev.x = sx | (sy << 16);
+    ev.y = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING;
+    ev.z += 1;
+    ev.w = 0;
+    *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+}
+
+__global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const uint8_t *sel, int sel_value, u64 seed)
+{
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
+    const size_t total = (size_t)a.batch * cells;
+    const WfCold *cold = a.cold;
+    const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
+    const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1), ppm = cold->p.ignite_ppm;
+    const u64 id0 = cold->p.env_id0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t e = (uint32_t)(i / cells), q = (uint32_t)(i % cells);
+        if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) continue;
+        const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec
+        const EnvKey key(seed, id0 + (u64)e, ev.z - 1u);
+        const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
+        uint32_t fuel = (uint32_t)fuel_lo;
+        if (span > 1u) fuel += below(key.draw(16u + q), span);
+        uint32_t ty = WF_GRASS, heat = 0, ag = 0;
+        if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
+        if (q == qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
+        if (ppm && ty == WF_GRASS && below(key.draw(16u + cells + q), 1000000u) < ppm) {
+            ty = WF_FIRE;
+            heat = WF_HEAT_FORCED;
+            const uint32_t x = q % W, y = q / W;
+            if (x == 0 || y == 0 || x == W - 1 || y == H - 1)
+                atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+        }
+        a.planes[(size_t)e * cells + q] = ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
+    }
+}
+
+}  // namespace
+
+hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s)
+{
+    const unsigned eb = (unsigned)((a.batch + 255) / 256);
+    hipLaunchKernelGGL(wf_big_reset_rec, dim3(eb), dim3(256), 0, s, a, sel, sel_value, seed);
+    const size_t total = (size_t)a.batch * a.H * a.W;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wf_big_reset_cells, dim3((unsigned)blocks), dim3(256), 0, s, a, sel, sel_value, seed);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 auto_seed, hipStream_t s)
+{
+    const unsigned eb = (unsigned)((a.batch + 255) / 256);
+    hipLaunchKernelGGL(wf_big_pre, dim3(eb), dim3(256), 0, s, a, mode);
+    if (a.hot_flags & WF_HOT_AUTO_RESET) {
+        hipError_t e = wf_launch_reset_big(a, mode, MODE_RESET, auto_seed, s);
+        if (e != hipSuccess) return e;
+    }
+    if (fam == WF_FAM_TILED) {
+        const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
+        hipLaunchKernelGGL(wf_step_tiled, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc);
+    } else {
+        const size_t total = (size_t)a.batch * a.H * a.W;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wf_step_cells, dim3((unsigned)blocks), dim3(256), 0, s, a, mode, acc);
+    }
+    hipLaunchKernelGGL(wf_big_post, dim3(eb), dim3(256), 0, s, a, mode, acc);
+    return hipGetLastError();
+}
