@@ -538,14 +538,20 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
     // cell that may be dug: destination of a move, or the own cell when digging is toggled on
     const uint32_t xd = istog ? ax : (inb ? nx : ax), yd = istog ? ay : (inb ? ny : ay);
     uint32_t ring = 0;
+    const uint32_t precheck0 = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
+    if (__ballot(precheck0 & running) != 0) {        // wave-uniform: nobody needs the ring otherwise
+        const uint32_t qx = istog ? qa : qd;
+        // edge flags of the centre cell: which ring cells fall off the grid
+        const uint32_t x0 = xd == 0u ? 1u : 0u, xl = xd == (uint32_t)(W - 1) ? 1u : 0u;
+        const uint32_t y0 = yd == 0u ? 1u : 0u, yl = yd == (uint32_t)(H - 1) ? 1u : 0u;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        constexpr int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
-        const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
-        const uint32_t rout = (((uint32_t)(W - 1) - rx) | rx | ((uint32_t)(H - 1) - ry) | ry) >> 31;
-        const uint32_t nq = (rout ^ 1u) * (ry * W + rx);
-        const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
-        ring |= ((rout ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
+        for (int r = 0; r < 8; ++r) {
+            constexpr int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
+            const uint32_t off = (DX[r] < 0 ? x0 : DX[r] > 0 ? xl : 0u) | (DY[r] < 0 ? y0 : DY[r] > 0 ? yl : 0u);
+            const uint32_t nq = off ? 0u : qx + (uint32_t)(DY[r] * W + DX[r]);
+            const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
+            ring |= ((off ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
+        }
     }
     const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u) & running;           // :146 traversable
     const uint32_t dfire = moved & (2u >> td);                                         // destination burning
@@ -652,13 +658,14 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
                     // reduce_fuel (environment.py:297-307)
                     const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
                     STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
-                    c[j] += lanebit(F) ? K_FIRE_STEP : 0u;                         // fuel -= 1, fire -> burnt ...
+                    // fuel -= 1 and fire -> burnt, unless still burning (type stays fire)
+                    const uint32_t d = lanebit(STILL[j]) ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
+                    c[j] += lanebit(F) ? d : 0u;
                 }
                 uint32_t ign_bits = 0;
                 static_for<4>([&](auto J) {
                     constexpr int j = decltype(J)::value;
                     using C = CM<W, H, j>;
-                    c[j] -= lanebit(STILL[j]) ? 1u : 0u;                           // ... unless still burning
                     // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294), branch-free so
                     // that every mask stays a wave-uniform scalar.  Row wrap: compile-time lane masks.
                     const u64 GR = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
