@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--ignite-ppm", type=int, default=0, help="extra pre-ignited cells per million at reset (config 4)")
     ap.add_argument("--noop", action="store_true", help="no agent actions (configs 2 and 4)")
+    ap.add_argument("--no-containment", action="store_true", help="experiment: containment test off")
     return ap.parse_args()
 
 
@@ -119,7 +120,7 @@ def main():
     S, B, K, Wm = args.size, args.batch, args.steps, args.warmup
     cells = B * S * S
     env = make_shard(B * world, S, rank=rank, world_size=world, device=local, seed=args.seed,
-                     auto_reset=True, fuel_range=(10, 40), containment=None, ignite_ppm=args.ignite_ppm)
+                     auto_reset=True, fuel_range=(10, 40), containment=(False if args.no_containment else None), ignite_ppm=args.ignite_ppm)
     lo = rank * B
     env.reset(seed=args.seed)
     total = Wm + K

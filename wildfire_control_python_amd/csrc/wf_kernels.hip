@@ -182,10 +182,12 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 }
 
 // Containment shortcut: removing a cell q from the passable set can only change which
-// cells are connected to the border when q is itself a border cell, or when the
-// passable cells on the 8-cell ring around q (cyclic order N,NE,E,SE,S,SW,W,NW;
-// off-grid = impassable) form >= 2 separate runs.  Otherwise any path through q
-// re-routes along the single run.  Lanes 0..7 each inspect one ring cell.
+// cells are connected to the border when q is itself a border cell, or when its
+// passable 4-neighbours are not all connected to each other without q.  The fused
+// kernel tests that on the 8-cell ring (passable ring cells in cyclic order
+// N,NE,E,SE,S,SW,W,NW form one run; lanes 0..7 each inspect one ring cell); the
+// single-step kernel counts the connected components exactly and refines the border case
+// (see wf_step_group).
 
 #ifndef WF_LB
 #define WF_LB 6   // minimum waves per SIMD the register allocator must leave room for
@@ -537,9 +539,15 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
     const uint32_t istog = toggling ? (act == 4u ? 1u : 0u) : 0u;
     // cell that may be dug: destination of a move, or the own cell when digging is toggled on
     const uint32_t xd = istog ? ax : (inb ? nx : ax), yd = istog ? ay : (inb ? ny : ay);
-    uint32_t ring = 0;
+    // Containment shortcut: gather the passability of the 8-ring (N,NE,E,SE,S,SW,W,NW) around
+    // the cell that may get dug; off-grid = impassable.
+    uint32_t ring = 0, bnmask = 0;
     const uint32_t precheck0 = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
-    if (__ballot(precheck0 & running) != 0) {        // wave-uniform: nobody needs the ring otherwise
+#ifdef WF_EXP_NOGATHER
+    if (false) {
+#else
+    if (__ballot(precheck0 & running) != 0) {        // wave-uniform: nobody needs the test otherwise
+#endif
         const uint32_t qx = istog ? qa : qd;
         // edge flags of the centre cell: which ring cells fall off the grid
         const uint32_t x0 = xd == 0u ? 1u : 0u, xl = xd == (uint32_t)(W - 1) ? 1u : 0u;
@@ -552,6 +560,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
             const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
             ring |= ((off ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
         }
+        // which 4-neighbours (ring bits 0,2,4,6 = N,E,S,W) are border cells themselves
+        const uint32_t ex = x0 | xl, ey = y0 | yl;
+        bnmask = (ex | (yd == 1u ? 1u : 0u)) | ((ey | (xd == (uint32_t)(W - 2) ? 1u : 0u)) << 2) |
+                 ((ex | (yd == (uint32_t)(H - 2) ? 1u : 0u)) << 4) | ((ey | (xd == 1u ? 1u : 0u)) << 6);
     }
     const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u) & running;           // :146 traversable
     const uint32_t dfire = moved & (2u >> td);                                         // destination burning
@@ -581,13 +593,28 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
     if (vis_before) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qa * 4u + 3u)) = 0;
     if (dug) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qd * 4u)) = (uint8_t)WF_DIRT;
     if (vis_after & running) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qa_new * 4u + 3u)) = 1;
-    // ring verdict: can this dig disconnect anything from the border?
+    // Verdict: can this dig change which cells reach the border?  Digging cell X re-routes
+    // nothing iff the passable 4-neighbours of X stay connected to each other around the ring
+    // (a passable diagonal connects its two even neighbours): components = #passable
+    // 4-neighbours - #connecting diagonals (the closed 8-ring gives 0).  A border cell X may in
+    // addition have been the only border cell its neighbours reached: harmless iff one of those
+    // neighbours is a border cell itself.  Exact; everything else triggers the flood in phase B.
     uint32_t ringflag;
     {
         const uint32_t onb = (((xd - 1u) | (yd - 1u) | ((uint32_t)(W - 2) - xd) | ((uint32_t)(H - 2) - yd)) >> 31);
-        const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
-        const uint32_t runs = (uint32_t)__popc(ring & ~rot);
-        ringflag = dug & (onb | (runs >> 1) | (runs >> 2)) & 1u;
+        const uint32_t even = ring & 0x55u;
+        const uint32_t eff = ring & 0xAAu & (even << 1) & ((even >> 1) | (even << 7));
+        const uint32_t comps = (uint32_t)__popc(even) - (uint32_t)__popc(eff);
+        const uint32_t local_fail = (comps + 0x7FFFFFFEu) >> 31;              // comps >= 2 (comps in 0..4)
+        const uint32_t border_fail = onb & min(even, 1u) & (min(ring & bnmask, 1u) ^ 1u);
+#ifdef WF_EXP_NOONB
+        ringflag = dug & local_fail & 1u + 0u * border_fail;   // timing experiment only: wrong results
+#else
+        ringflag = dug & (local_fail | border_fail) & 1u;
+#endif
+#ifdef WF_EXP_NORING
+        ringflag = 0;   // timing experiment only: wrong results
+#endif
     }
     const uint32_t precheck = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
     const uint32_t Pv = running | (precheck << 1) | (((fl >> 7) & 1u) << 2) | (ringflag << 3);
