@@ -108,7 +108,8 @@ struct EnvS {        // wave-uniform scalars of one environment
 // t/u/h: type, fuel (unsigned byte), heat quanta of the lane's 4 cells.
 template <int W, int H>
 __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint32_t e, uint32_t lane,
-                                           uint32_t (&t)[4], uint32_t (&u)[4], uint32_t (&h)[4], EnvS &s)
+                                           uint32_t (&t)[4], uint32_t (&u)[4], uint32_t (&h)[4], EnvS &s,
+                                           u64 *reach_e)
 {
     constexpr int CELLS = W * H;
     cold_ptr cold = (cold_ptr)(uintptr_t)cold_g;
@@ -139,9 +140,22 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
         u[j] = active ? ((uint32_t)fuel & 0xffu) : 0u;
         h[j] = active ? heat : 0u;
     });
+    // Border reachability of a fresh grid is known in closed form: every cell except the
+    // agent's (dug) spawn cell - removing one cell cannot disconnect a grid - so the first
+    // containment test of the episode needs no flood.
+    if (lane == 0) {
+        u64 rb[4];
+        static_for<4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            rb[j] = CM<W, H, j>::VALID & ~(((qs & 3u) == (uint32_t)j) ? (1ull << (qs >> 2)) : 0ull);
+        });
+        ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(reach_e);
+        rp[0] = make_ulonglong2(rb[0], rb[1]);
+        rp[1] = make_ulonglong2(rb[2], rb[3]);
+    }
     s.ax = sx;
     s.ay = sy;
-    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | (onborder ? WF_F_BORDER : 0u);
+    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | WF_F_REACH_VALID | (onborder ? WF_F_BORDER : 0u);
     s.episode += 1;
     s.tick = 0;
 }
@@ -286,8 +300,17 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                     uint32_t e_pin = e;
                     asm volatile("" : "+s"(cold), "+s"(e_pin));
                     cold_ptr cc = (cold_ptr)(uintptr_t)cold;
-                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s);
+                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
                     ax = s.ax; ay = s.ay; fl = s.fl; episode = s.episode; tick = s.tick;
+                    {   // the fresh bitboards were written with vector stores: keep them in registers,
+                        // never re-read them through the scalar cache inside this launch
+                        const uint32_t qs = s.ay * W + s.ax;
+                        static_for<4>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            RBK[j] = CM<W, H, j>::VALID & ~(((qs & 3u) == (uint32_t)j) ? (1ull << (qs >> 2)) : 0ull);
+                        });
+                        rb_have = true;
+                    }
                     dirty = true;
                     done = 0;
                 }
@@ -658,7 +681,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
                     asm volatile("" : "+s"(cold), "+s"(e_pin));
                     cold_ptr cc = (cold_ptr)(uintptr_t)cold;
                     uint32_t t[4], u[4], h[4];
-                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s);
+                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
                     const uint32_t qs = s.ay * W + s.ax;
                     uint32_t r[4];
 #pragma unroll
@@ -795,7 +818,7 @@ __global__ __launch_bounds__(256) void wf_reset_wave(const WfArgs a)
         s.episode = rfl(ev.z);
         s.tick = 0;
         uint32_t t[4], u[4], h[4];
-        reset_regs<W, H>(a.cold, a.reset_seed, e, lane, t, u, h, s);
+        reset_regs<W, H>(a.cold, a.reset_seed, e, lane, t, u, h, s, a.reach + (size_t)e * 4);
         const uint32_t qa = s.ay * W + s.ax;
         uint32_t r[4];
 #pragma unroll
