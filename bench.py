@@ -170,6 +170,26 @@ def main():
         fused = {"steps_per_launch": F, "launches": reps,
                  "cell_updates_per_s_per_gpu": cells * F * reps / (f_ms * 1e-3)}
 
+    # extra: step + observation.  Fused (the step kernel writes World.get_state() itself) against
+    # the same step followed by the stand-alone observation kernel.
+    obs_extra = None
+    if "group" in env.kernel_name:
+        d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
+        torch.cuda.synchronize()
+        n_o = min(K, 100)
+        env.step_device(d_act[0], 1, d_rew, d_done, update_mask=1, d_obs=d_obs)
+        env.timer_start()
+        for s in range(n_o):
+            env.step_device(d_act[Wm + s], 1, d_rew, d_done, update_mask=1, d_obs=d_obs)
+        fused_ms = env.timer_stop()
+        env.timer_start()
+        for s in range(n_o):
+            env.step_device(d_act[Wm + s], 1, d_rew, d_done, update_mask=1)
+            env.get_state_device(d_obs)
+        sep_ms = env.timer_stop()
+        obs_extra = {"fused_us_per_step": fused_ms / n_o * 1e3, "separate_us_per_step": sep_ms / n_o * 1e3,
+                     "fused_cell_updates_per_s": cells * n_o / (fused_ms * 1e-3)}
+
     # extra: the synchronous host-buffer entry point (numpy actions in, reward/done out): PCIe and
     # host synchronisation included.  Reported for completeness; it is never `value`.
     host_api = None
@@ -222,6 +242,8 @@ def main():
         }
         if fused:
             out["fused"] = fused
+        if obs_extra:
+            out["step_plus_observation"] = obs_extra
         if host_api:
             out["host_buffer_api"] = host_api
         if world == 1 and not args.no_cpu_baseline:

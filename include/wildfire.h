@@ -137,6 +137,14 @@ int wf_step(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mas
 int wf_step_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
                    double *d_reward, uint8_t *d_done);
 
+/* The same steps, and World.get_state() of the resulting state written in the same launch
+ * (the grid is in registers anyway): obs int8 (batch, W, H, 3).  This is what
+ * `[get_state(), get_reward(), not RUNNING, {}]` of forest_fire.py:46-49 costs per step. */
+int wf_step_obs(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mask,
+                double *reward, uint8_t *done, int8_t *obs);
+int wf_step_obs_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
+                       double *d_reward, uint8_t *d_done, int8_t *d_obs);
+
 /* World.get_state() (environment.py:399-402) for the whole batch. */
 int wf_get_state(wf_ctx *ctx, int8_t *obs);
 int wf_get_state_device(wf_ctx *ctx, int8_t *d_obs);

@@ -143,6 +143,24 @@ def test_fused_steps_equal_single_steps(wf):
     e2.close()
 
 
+def test_fused_multi_step_observation(wf):
+    """wf_step_obs with n_steps > 1: the observation is that of the final state."""
+    import ctypes
+    from wildfire_control_python_amd import _native as N
+    B = 200
+    env = wf.BatchedForestFire(B, size=12, fuel_range=(4, 9), auto_reset=True, seed=8)
+    env.reset(seed=8)
+    a = np.random.default_rng(1).integers(0, 5, size=(24, B)).astype(np.int8)
+    for t0 in (0, 8, 16):
+        reward = np.empty((8, B)); done = np.empty((8, B), dtype=np.uint8)
+        obs = np.empty((B, 12, 12, 3), dtype=np.int8)
+        rc = env._lib.wf_step_obs(env._h, N.ptr(np.ascontiguousarray(a[t0:t0 + 8])), 8, ctypes.c_uint64(255),
+                                  N.ptr(reward), N.ptr(done), N.ptr(obs))
+        assert rc == 0
+        np.testing.assert_array_equal(obs, O.get_state(env.download()[0]))
+    env.close()
+
+
 def test_a_speed_two_updates_every_other_step(wf):
     B = 128
     env = wf.BatchedForestFire(B, size=10, metadata={"a_speed": 2, "a_speed_iter": 2})
@@ -199,7 +217,7 @@ def test_auto_reset_matches_oracle_reset(wf):
     resets = 0
     for t in range(80):
         a = rng.integers(0, 4, size=B).astype(np.int8)
-        _, r, d, _ = env.step(a)
+        obs, r, d, _ = env.step(a)
         stopped = (envs["flags"] & O.F_RUNNING) == 0
         ro, do = O.step(planes, envs, a, op)
         if stopped.any():           # next-step autoreset: the step resets instead, reward 0, done 0
@@ -207,6 +225,8 @@ def test_auto_reset_matches_oracle_reset(wf):
             ro[stopped], do[stopped] = 0.0, 0
             resets += int(stopped.sum())
         gp, ge = env.download()
+        np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"fused obs t={t}")
+        np.testing.assert_array_equal(env.get_state(), obs, err_msg=f"standalone obs t={t}")
         np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
         np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
         np.testing.assert_array_equal(r, ro)
@@ -223,9 +243,10 @@ def test_frozen_after_done_and_reset_mask(wf):
         _, r, d, _ = env.step(None)
     assert d.all()
     p0, e0 = env.download()
-    _, r, d, _ = env.step(np.zeros(B, dtype=np.int8))
+    obs, r, d, _ = env.step(np.zeros(B, dtype=np.int8))
     p1, e1 = env.download()
     np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(obs, O.get_state(p1), err_msg="fused obs of frozen envs")
     assert (r == 0).all() and d.all()
     mask = np.zeros(B, dtype=np.uint8)
     mask[::2] = 1

@@ -61,6 +61,8 @@ SYMBOLS = [
     ("wf_reset_device", _i, [_vp, _vp, _u64]),
     ("wf_step", _i, [_vp, _vp, _i, _u64, _vp, _vp]),
     ("wf_step_device", _i, [_vp, _vp, _i, _u64, _vp, _vp]),
+    ("wf_step_obs", _i, [_vp, _vp, _i, _u64, _vp, _vp, _vp]),
+    ("wf_step_obs_device", _i, [_vp, _vp, _i, _u64, _vp, _vp, _vp]),
     ("wf_get_state", _i, [_vp, _vp]),
     ("wf_get_state_device", _i, [_vp, _vp]),
     ("wf_sync", _i, [_vp]),

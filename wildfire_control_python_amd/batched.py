@@ -227,16 +227,25 @@ class BatchedForestFire:
         (forest_fire.py:30-49 with a batch axis)."""
         if actions is not None and not isinstance(actions, np.ndarray):
             actions = np.array([encode_action(a) for a in actions], dtype=np.int8)
-        reward, done = self.step_many(actions, 1)
-        return [self.get_state(), reward[0], done[0], {}]
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.int8)
+            assert actions.shape == (self.batch,)
+        reward = np.empty(self.batch, dtype=np.float64)
+        done = np.empty(self.batch, dtype=np.uint8)
+        obs = np.empty((self.batch, self.width, self.height, 3), dtype=np.int8)
+        # one launch: the observation is written by the step kernel itself
+        self._ck(self._lib.wf_step_obs(self._h, N.ptr(actions), 1, ctypes.c_uint64(self._update_mask(1)),
+                                       N.ptr(reward), N.ptr(done), N.ptr(obs)), "wf_step_obs")
+        return [obs, reward, done.astype(bool), {}]
 
-    def step_device(self, d_actions=None, n_steps=1, d_reward=None, d_done=None, update_mask=None):
-        """Asynchronous step on device buffers (torch tensors or raw pointers)."""
+    def step_device(self, d_actions=None, n_steps=1, d_reward=None, d_done=None, update_mask=None, d_obs=None):
+        """Asynchronous step on device buffers (torch tensors or raw pointers); with d_obs the
+        observation of the resulting state is written by the same launch."""
         if update_mask is None:
             update_mask = self._update_mask(n_steps)
-        self._ck(self._lib.wf_step_device(self._h, N.ptr(d_actions), int(n_steps),
-                                          ctypes.c_uint64(update_mask), N.ptr(d_reward), N.ptr(d_done)),
-                 "wf_step_device")
+        self._ck(self._lib.wf_step_obs_device(self._h, N.ptr(d_actions), int(n_steps),
+                                              ctypes.c_uint64(update_mask), N.ptr(d_reward), N.ptr(d_done),
+                                              N.ptr(d_obs)), "wf_step_obs_device")
 
     # ----------------------------------------------------------------- observation
     def get_state(self):

@@ -337,10 +337,17 @@ int wf_reset(wf_ctx *c, const uint8_t *mask, uint64_t seed)
 int wf_step_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t update_mask,
                    double *d_reward, uint8_t *d_done)
 {
+    return wf_step_obs_device(c, d_actions, n_steps, update_mask, d_reward, d_done, nullptr);
+}
+
+int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t update_mask,
+                       double *d_reward, uint8_t *d_done, int8_t *d_obs)
+{
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->fam == WF_FAM_WAVE) {
         WfArgs a = base_args(c);
+        a.obs = d_obs;                 // fused into the step kernel
         a.actions = d_actions;
         a.reward = d_reward;
         a.done = d_done;
@@ -361,20 +368,30 @@ int wf_step_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t upd
         HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode, c->d_acc, c->p.seed, c->stream));
         uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t;   // ping-pong
     }
+    if (d_obs) HIP_TRY(c, wf_launch_get_state(c->planes, d_obs, c->batch, c->H, c->W, c->stream));
     return WF_OK;
 }
 
 int wf_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
             double *reward, uint8_t *done)
 {
+    return wf_step_obs(c, actions, n_steps, update_mask, reward, done, nullptr);
+}
+
+int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
+                double *reward, uint8_t *done, int8_t *obs)
+{
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
     int rc = ensure_staging(c, n_steps);
     if (rc != WF_OK) return rc;
     const size_t n = (size_t)n_steps * (size_t)c->batch;
     if (actions) HIP_TRY(c, hipMemcpyAsync(c->d_actions, actions, n, hipMemcpyHostToDevice, c->stream));
-    rc = wf_step_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask,
-                        reward ? c->d_reward : nullptr, done ? c->d_done : nullptr);
+    const size_t nobs = (size_t)c->batch * c->H * c->W * 3;
+    if (obs && !c->d_obs) HIP_TRY(c, hipMalloc((void **)&c->d_obs, nobs));
+    rc = wf_step_obs_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask,
+                            reward ? c->d_reward : nullptr, done ? c->d_done : nullptr, obs ? c->d_obs : nullptr);
     if (rc != WF_OK) return rc;
+    if (obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));
     if (reward) HIP_TRY(c, hipMemcpyAsync(reward, c->d_reward, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (done) HIP_TRY(c, hipMemcpyAsync(done, c->d_done, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

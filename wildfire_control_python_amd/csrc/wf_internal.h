@@ -38,6 +38,7 @@ struct WfArgs {
     uint8_t *done;           // (n_steps, batch) or nullptr
     const uint8_t *mask;     // reset: per-env mask or nullptr
     const WfCold *cold;      // device copy of the rarely needed parameters
+    int8_t *obs;             // optional fused observation output (batch, W, H, 3) of the final state
     int32_t batch, H, W, n_steps;
     u64 update_mask;
     u64 reset_seed;          // wf_reset: explicit seed (auto_reset uses cold->p.seed)

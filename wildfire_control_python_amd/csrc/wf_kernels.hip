@@ -178,6 +178,58 @@ __device__ __forceinline__ void flood(u64 (&R)[4], const u64 (&P)[4])
 }
 
 // ----------------------------------------------------------------------------
+// fused observation: World.get_state() (environment.py:399-402) from registers
+// ----------------------------------------------------------------------------
+// obs[b][x][y][k] = (agent_pos, type == fire, fire_mobility != inf): the grid is transposed
+// ([x][y] vs the planes' [y][x]) and 3 bytes per cell, so each lane drops its 4 cells'
+// byte triples at their transposed offsets of a per-wave LDS image of the env's 3*W*H
+// output bytes, and the image leaves as coalesced 16-byte stores.
+template <int W, int H>
+struct ObsGeo {
+    static constexpr int BYTES = W * H * 3;
+    static constexpr int PAD = (BYTES + 15) & ~15;
+    static constexpr int FULL = BYTES / 16;          // lanes storing 16 bytes
+    static constexpr int TAIL = BYTES % 16;          // bytes of the last partial lane (multiple of 4)
+};
+
+template <int W, int H>
+__device__ __forceinline__ void obs_offsets(uint32_t lane, uint32_t (&oj)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t q = 4u * lane + (uint32_t)j, x = q % W, y = q / W;
+        oj[j] = (x * H + y) * 3u;
+    }
+    asm volatile("" : "+v"(oj[0]), "+v"(oj[1]), "+v"(oj[2]), "+v"(oj[3]));
+}
+
+// c[j] = packed cell words (type in byte 0, agent_pos in byte 3); call with cell-owning lanes only
+template <int W, int H>
+__device__ __forceinline__ void emit_obs(uint8_t *lds, int8_t *obs_e, const uint32_t (&c)[4],
+                                         const uint32_t (&oj)[4], uint32_t lane)
+{
+    using G = ObsGeo<W, H>;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t t = c[j] & 0xffu;
+        lds[oj[j]] = (uint8_t)(c[j] >> 24);                       // agent_pos
+        lds[oj[j] + 1u] = (uint8_t)((2u >> t) & 1u);              // type == fire
+        lds[oj[j] + 2u] = (uint8_t)((7u >> t) & 1u);              // not dirt / water
+    }
+    if (lane < (uint32_t)G::FULL) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(lds + lane * 16u);
+        // the env stride 3*W*H is only 4-byte aligned: a 16-byte store with 4-byte alignment
+        struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+        *reinterpret_cast<U4 *>(obs_e + lane * 16u) = U4{ v.x, v.y, v.z, v.w };
+    } else if (G::TAIL && lane == (uint32_t)G::FULL) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + lane * 16u);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(obs_e + lane * 16u);
+#pragma unroll
+        for (int k = 0; k < G::TAIL / 4; ++k) dst[k] = src[k];
+    }
+}
+
+// ----------------------------------------------------------------------------
 // the step kernel: n_steps x ForestFire.step() (forest_fire.py:30-49) per env
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bperm(uint32_t byte_addr, uint32_t v)
@@ -235,6 +287,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
     // opaque: stop the optimiser from turning this back into 64-bit scalar masks
     asm volatile("" : "+v"(geo));
     const uint32_t lane_off = lane * 16u;
+    __shared__ __attribute__((aligned(16))) uint8_t sObs[4][ObsGeo<W, H>::PAD];
+    uint8_t *obs_lds = sObs[threadIdx.x >> 6];
+    uint32_t oj[4];
+    obs_offsets<W, H>(lane, oj);
 
     uint4 raw_next = make_uint4(0, 0, 0, 0), ev_next = make_uint4(0, 0, 0, 0);
     uint32_t act_pref = 0xffu;
@@ -486,6 +542,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | (sel == (uint32_t)j ? (1u << 24) : 0u);
             if (active)
                 *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.planes) + poff) = make_uint4(r[0], r[1], r[2], r[3]);
+            if (a.obs && active) emit_obs<W, H>(obs_lds, a.obs + (size_t)e * (CELLS * 3), r, oj, lane);
+        } else if (a.obs && active) {      // frozen env: observation of the unchanged grid
+            const uint32_t cf[4] = { raw.x, raw.y, raw.z, raw.w };
+            emit_obs<W, H>(obs_lds, a.obs + (size_t)e * (CELLS * 3), cf, oj, lane);
         }
         if (lane == 0) {
             if (dirty)
@@ -661,6 +721,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
     }
     asm volatile("" : "+v"(bgeo));
     const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
+    __shared__ __attribute__((aligned(16))) uint8_t sObs[4][ObsGeo<W, H>::PAD];
+    uint8_t *obs_lds = sObs[threadIdx.x >> 6];
+    uint32_t oj[4];
+    obs_offsets<W, H>(lane, oj);
     if (active) {
         uint4 raw_next = *reinterpret_cast<const uint4 *>(planes_b + (e0 * ENV_BYTES + lane_off));
         for (uint32_t k = 0; k < ng; ++k) {
@@ -688,12 +752,16 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
                     for (int j = 0; j < 4; ++j)
                         r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | ((lane == (qs >> 2) && (qs & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
                     *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(r[0], r[1], r[2], r[3]);
+                    if (a.obs) emit_obs<W, H>(obs_lds, a.obs + (size_t)e * (CELLS * 3), r, oj, lane);
                     ax = (lane == k ? s.ax : ax);
                     ay = (lane == k ? s.ay : ay);
                     fl = (lane == k ? s.fl : fl);
                     episode = (lane == k ? s.episode : episode);
                     tick = (lane == k ? s.tick : tick);
                     R = RB_WASRESET;
+                } else if (a.obs) {      // frozen: the observation of the unchanged grid
+                    const uint32_t cf[4] = { raw.x, raw.y, raw.z, raw.w };
+                    emit_obs<W, H>(obs_lds, a.obs + (size_t)e * (CELLS * 3), cf, oj, lane);
                 }
                 Rv = (lane == k ? R : Rv);
                 continue;
@@ -772,6 +840,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
                 R |= healthy << RB_HEALTHY_SHIFT;
             }
             *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(c[0], c[1], c[2], c[3]);
+            if (a.obs) emit_obs<W, H>(obs_lds, a.obs + (size_t)e * (CELLS * 3), c, oj, lane);
             Rv = (lane == k ? R : Rv);
         }
     }
@@ -829,6 +898,26 @@ __global__ __launch_bounds__(256) void wf_reset_wave(const WfArgs a)
             reinterpret_cast<uint4 *>(a.planes + (size_t)e * CELLS)[lane] = make_uint4(r[0], r[1], r[2], r[3]);
         if (lane == 0)
             *reinterpret_cast<uint4 *>(&a.envs[e]) = make_uint4(s.ax | (s.ay << 16), s.fl, s.episode, s.tick);
+    }
+}
+
+// World.get_state() for the wave family: one env per wave iteration, LDS transpose, 16-byte stores.
+template <int W, int H>
+__global__ __launch_bounds__(256) void wf_get_state_wave(const uint32_t *__restrict__ planes, int8_t *__restrict__ obs, int batch)
+{
+    constexpr int CELLS = W * H, LANES = CELLS / 4;
+    __shared__ __attribute__((aligned(16))) uint8_t sObs[4][ObsGeo<W, H>::PAD];
+    uint8_t *obs_lds = sObs[threadIdx.x >> 6];
+    const uint32_t lane = __lane_id();
+    const uint32_t wave0 = rfl(blockIdx.x * 4u + (threadIdx.x >> 6)), nwaves = gridDim.x * 4u;
+    uint32_t oj[4];
+    obs_offsets<W, H>(lane, oj);
+    if (lane < (uint32_t)LANES) {
+        for (uint32_t e = wave0; e < (uint32_t)batch; e += nwaves) {
+            const uint4 raw = reinterpret_cast<const uint4 *>(planes)[(size_t)e * LANES + lane];
+            const uint32_t c[4] = { raw.x, raw.y, raw.z, raw.w };
+            emit_obs<W, H>(obs_lds, obs + (size_t)e * (CELLS * 3), c, oj, lane);
+        }
     }
 }
 
@@ -935,6 +1024,15 @@ hipError_t wf_launch_invalidate_reach(wf_env *envs, int batch, hipStream_t s)
 
 hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, int H, int W, hipStream_t s)
 {
+#define X(w, h)                                                                                         \
+    if (W == w && H == h) {                                                                             \
+        int blocks = (batch + 3) / 4;                                                                   \
+        if (blocks > 2048) blocks = 2048;                                                               \
+        hipLaunchKernelGGL((wf_get_state_wave<w, h>), dim3(blocks), dim3(256), 0, s, planes, obs, batch); \
+        return hipGetLastError();                                                                       \
+    }
+    WF_WAVE_SHAPES(X)
+#undef X
     const size_t total = (size_t)batch * H * W;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
