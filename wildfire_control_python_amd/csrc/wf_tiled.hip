@@ -28,6 +28,22 @@ using namespace wfdev;
 enum { MODE_COPY = 0, MODE_STEP = 1, MODE_RESET = 2 };
 constexpr int TR = 16;   // rows per wave strip
 
+// World.reset(), record part (environment.py:186-212): spawn point from the counter-based stream
+__device__ __forceinline__ void reset_record(const WfArgs &a, uint32_t e, u64 seed)
+{
+    const WfCold *cold = a.cold;
+    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    const EnvKey key(seed, cold->p.env_id0 + (u64)e, ev.z);
+    const uint32_t r = below(key.draw(0), 3u);
+    const uint32_t k = below(key.draw(1), (uint32_t)cold->spawn.n[r]);
+    const uint32_t sx = (uint32_t)a.W / 2u + (int)cold->spawn.dx[r][k], sy = (uint32_t)a.H / 2u + (int)cold->spawn.dy[r][k];
+    ev.x = sx | (sy << 16);
+    ev.y = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING;
+    ev.z += 1;
+    ev.w = 0;
+    *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+}
+
 // ---------------------------------------------------------------------------- pre
 __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
 {
@@ -41,6 +57,7 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
         mode[e] = rs ? MODE_RESET : MODE_COPY;     // frozen: the reference is never stepped after done
         if (a.reward) a.reward[e] = 0.0;
         if (a.done) a.done[e] = rs ? 0 : 1;
+        if (rs) reset_record(a, e, a.cold->p.seed);   // the cells follow in wf_big_reset_cells
         return;
     }
     mode[e] = MODE_STEP;
@@ -132,6 +149,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const uint32_t ign = (uint32_t)a.ignite_count;
     const bool step = (mode[e] == MODE_STEP) && (a.update_mask & 1ull);
     const bool reduce = mode[e] == MODE_STEP;
+    // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
     uint4 *dst = reinterpret_cast<uint4 *>(a.planes_out) + (size_t)e * H * LW + lane;
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
@@ -141,8 +159,8 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     u64 Sf[4] = { 0, 0, 0, 0 }, Sl[4] = { 0, 0, 0, 0 };
     if (has_rows) {
         if (active) {
-            first = src[(size_t)r0 * LW];
-            last = src[(size_t)(r1 - 1) * LW];
+            first = src[r0 * LW];
+            last = src[(r1 - 1u) * LW];
         }
         still_masks(first, Sf);
         still_masks(last, Sl);
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
             }
         } else {   // workgroup's outer halo: from global memory
             uint4 up = inert;
-            if (active) up = src[(size_t)(r0 - 1) * LW];
+            if (active) up = src[(r0 - 1u) * LW];
             still_masks(up, Sp);
         }
     }
@@ -178,21 +196,22 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
             }
         } else {
             uint4 dn = inert;
-            if (active) dn = src[(size_t)r1 * LW];
+            if (active) dn = src[r1 * LW];
             still_masks(dn, Sb);
         }
     }
 
     // ---- sweep
     uint32_t anyfire = 0, bhit = 0, healthy = 0;
+    u64 ign_x0 = 0, ign_xl = 0;
     uint4 cur = first, nxt = inert;
     u64 Sc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) Sc[j] = Sf[j];
-    if (r0 + 1 < r1 && active) nxt = src[(size_t)(r0 + 1) * LW];
+    if (r0 + 1 < r1 && active) nxt = src[(r0 + 1u) * LW];
     for (uint32_t r = r0; r < r1; ++r) {
         uint4 nn = inert;                                        // prefetch row r+2
-        if (r + 2 < r1 && active) nn = src[(size_t)(r + 2) * LW];
+        if (r + 2 < r1 && active) nn = src[(r + 2u) * LW];
         u64 Sn[4];
         if (r + 1 < r1) still_masks(nxt, Sn);
         else {
@@ -202,8 +221,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
         uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
         u64 FIRE[4], GR[4];
         if (step) {
-            const bool edge_row = (r == 0) || (r == H - 1);
-            u64 border_hit = 0;
+            u64 anyign = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
@@ -219,13 +237,14 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
                 const u64 IGN = G & __ballot(cnt >= room);                     // apply_heat_from_to :278-294
                 const uint32_t cn = c[j] + (min(cnt, room) << 16) + (lanebit(IGN) ? 1u : 0u);
                 c[j] = lanebit(G) ? cn : c[j];
-                // set_fire_to :245-246: border = first/last row, x == 0, x == W-1
-                const u64 bm = edge_row ? ~0ull : (j == 0 ? 1ull : (j == 3 ? (1ull << (LW - 1)) : 0ull));
-                border_hit |= IGN & bm;
+                anyign |= IGN;
+                if (j == 0) ign_x0 |= IGN;                                      // cells with x == 0 (lane 0)
+                if (j == 3) ign_xl |= IGN;                                      // cells with x == W-1 (lane LW-1)
                 FIRE[j] = Sc[j] | IGN;
                 GR[j] = G & ~IGN;
             }
-            bhit |= border_hit ? 1u : 0u;
+            // set_fire_to :245-246: first / last row of the grid are border rows
+            if ((r == 0 || r == H - 1) && anyign) bhit = 1;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -237,12 +256,13 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
             anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
             healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
         }
-        if (active) dst[(size_t)r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
+        if (active) dst[r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Sp[j] = Sc[j]; Sc[j] = Sn[j]; }
         cur = nxt;
         nxt = nn;
     }
+    bhit |= ((ign_x0 & 1ull) | (ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
     if (reduce && lane == 0) {
         const uint32_t A = anyfire | (bhit << 1);
         if (A) atomicOr(&acc[2 * e], A);
@@ -305,33 +325,24 @@ __global__ __launch_bounds__(256) void wf_big_reset_rec(const WfArgs a, const ui
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (uint32_t)a.batch) return;
     if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) return;
-    const WfCold *cold = a.cold;
-    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
-    const EnvKey key(seed, cold->p.env_id0 + (u64)e, ev.z);
-    const uint32_t r = below(key.draw(0), 3u);
-    const uint32_t k = below(key.draw(1), (uint32_t)cold->spawn.n[r]);
-    const uint32_t sx = (uint32_t)a.W / 2u + (int)cold->spawn.dx[r][k], sy = (uint32_t)a.H / 2u + (int)cold->spawn.dy[r][k];
-    ev.x = sx | (sy << 16);
-    ev.y = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING;
-    ev.z += 1;
-    ev.w = 0;
-    *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+    reset_record(a, e, seed);
 }
 
 __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const uint8_t *sel, int sel_value, u64 seed)
 {
+    // one workgroup per environment: environments that are not being reset cost one load
+    const uint32_t e = blockIdx.x;
+    if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) return;
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
-    const size_t total = (size_t)a.batch * cells;
     const WfCold *cold = a.cold;
     const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
     const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1), ppm = cold->p.ignite_ppm;
-    const u64 id0 = cold->p.env_id0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const uint32_t e = (uint32_t)(i / cells), q = (uint32_t)(i % cells);
-        if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) continue;
-        const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec
-        const EnvKey key(seed, id0 + (u64)e, ev.z - 1u);
-        const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
+    const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec
+    const EnvKey key(seed, cold->p.env_id0 + (u64)e, ev.z - 1u);
+    const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
+    uint32_t *pe = a.planes + (size_t)e * cells;
+    bool border_fire = false;
+    for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
         uint32_t fuel = (uint32_t)fuel_lo;
         if (span > 1u) fuel += below(key.draw(16u + q), span);
         uint32_t ty = WF_GRASS, heat = 0, ag = 0;
@@ -341,23 +352,27 @@ __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const 
             ty = WF_FIRE;
             heat = WF_HEAT_FORCED;
             const uint32_t x = q % W, y = q / W;
-            if (x == 0 || y == 0 || x == W - 1 || y == H - 1)
-                atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+            border_fire |= (x == 0 || y == 0 || x == W - 1 || y == H - 1);
         }
-        a.planes[(size_t)e * cells + q] = ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
+        pe[q] = ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
     }
+    if (__ballot(border_fire) && __lane_id() == 0)
+        atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
 }
 
 }  // namespace
+
+static hipError_t launch_reset_cells(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s)
+{
+    hipLaunchKernelGGL(wf_big_reset_cells, dim3((unsigned)a.batch), dim3(256), 0, s, a, sel, sel_value, seed);
+    return hipGetLastError();
+}
 
 hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s)
 {
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_reset_rec, dim3(eb), dim3(256), 0, s, a, sel, sel_value, seed);
-    const size_t total = (size_t)a.batch * a.H * a.W;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(wf_big_reset_cells, dim3((unsigned)blocks), dim3(256), 0, s, a, sel, sel_value, seed);
+    hipLaunchKernelGGL(wf_big_reset_cells, dim3((unsigned)a.batch), dim3(256), 0, s, a, sel, sel_value, seed);
     return hipGetLastError();
 }
 
@@ -366,7 +381,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_pre, dim3(eb), dim3(256), 0, s, a, mode);
     if (a.hot_flags & WF_HOT_AUTO_RESET) {
-        hipError_t e = wf_launch_reset_big(a, mode, MODE_RESET, auto_seed, s);
+        hipError_t e = launch_reset_cells(a, mode, MODE_RESET, auto_seed, s);
         if (e != hipSuccess) return e;
     }
     if (fam == WF_FAM_TILED) {
