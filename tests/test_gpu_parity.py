@@ -369,3 +369,21 @@ def test_full_size_properties_65536x14x14(wf):
     np.testing.assert_array_equal(prev, p2)
     for e in (big, big2, small):
         e.close()
+
+
+# ---------------------------------------------------------------- consumers of the path
+@pytest.mark.parametrize("algo", ["DQN", "SARSA", "DDQN", "DSARSA"])
+def test_batched_learner_runs_on_the_device_api(wf, algo):
+    """The four value-based learners of the reference, batched, drive the env through
+    wf_step_obs_device with torch tensors (no host round trip) and learn something finite."""
+    import torch
+    env = wf.BatchedForestFire(512, size=10, auto_reset=True, seed=3)
+    L = wf.BatchedLearner(env, algo, replay_capacity=8192, batch_size=64, store_per_step=256)
+    w0 = [p.detach().clone() for p in L.model.parameters()]
+    logs = L.learn(60)
+    assert len(logs["loss"]) > 40 and all(np.isfinite(logs["loss"]))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(w0, L.model.parameters()))
+    assert L.m_len > 1000 and logs["finished_episodes"] >= 0
+    # the observations the learner saw are the environment's observations
+    np.testing.assert_array_equal(L.obs.cpu().numpy(), env.get_state())
+    env.close()

@@ -160,3 +160,27 @@ def test_two_rank_sharding_is_shard_count_independent():
     for t in range(30):
         O.step(planes, envs, acts[t], p)
     np.testing.assert_array_equal(sharded, planes)
+
+
+def test_learner_targets_follow_the_reference_rule():
+    """Regression targets of DQN.py:161-180 / DQN_SARSA.py:108-127 on a tiny CPU batch."""
+    import torch
+    from wildfire_control_python_amd.learner import make_network, td_targets
+    torch.manual_seed(0)
+    for dueling in (False, True):
+        net = make_network(torch, 10, 10, 3, 4, dueling)
+        s, sp = torch.rand(6, 10, 10, 3), torch.rand(6, 10, 10, 3)
+        a = torch.tensor([0, 1, 2, 3, 0, 1]); ap = torch.tensor([3, 2, 1, 0, 3, 2])
+        r = torch.tensor([-1.0, -1.0, 1000.0, -1000.0, -1.0, 500.0])
+        done = torch.tensor([False, False, False, True, False, True])
+        with torch.no_grad():
+            q, qn = net(s), net(sp)
+        y = td_targets(torch, net, s, a, r, sp, ap, done, 0.999, sarsa=False)
+        ys = td_targets(torch, net, s, a, r, sp, ap, done, 0.999, sarsa=True)
+        for i in range(6):
+            other = [k for k in range(4) if k != int(a[i])]
+            assert torch.equal(y[i, other], q[i, other]) and torch.equal(ys[i, other], q[i, other])
+            exp = r[i] if done[i] else r[i] + 0.999 * qn[i].max()
+            exps = r[i] if done[i] else r[i] + 0.999 * qn[i, ap[i]]
+            assert torch.isclose(y[i, a[i]], exp) and torch.isclose(ys[i, a[i]], exps)
+        assert net(s).shape == (6, 4)
