@@ -626,11 +626,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
     // the cell that may get dug; off-grid = impassable.
     uint32_t ring = 0, bnmask = 0;
     const uint32_t precheck0 = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
-#ifdef WF_EXP_NOGATHER
-    if (false) {
-#else
     if (__ballot(precheck0 & running) != 0) {        // wave-uniform: nobody needs the test otherwise
-#endif
         const uint32_t qx = istog ? qa : qd;
         // edge flags of the centre cell: which ring cells fall off the grid
         const uint32_t x0 = xd == 0u ? 1u : 0u, xl = xd == (uint32_t)(W - 1) ? 1u : 0u;
@@ -690,14 +686,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
         const uint32_t comps = (uint32_t)__popc(even) - (uint32_t)__popc(eff);
         const uint32_t local_fail = (comps + 0x7FFFFFFEu) >> 31;              // comps >= 2 (comps in 0..4)
         const uint32_t border_fail = onb & min(even, 1u) & (min(ring & bnmask, 1u) ^ 1u);
-#ifdef WF_EXP_NOONB
-        ringflag = dug & local_fail & 1u + 0u * border_fail;   // timing experiment only: wrong results
-#else
         ringflag = dug & (local_fail | border_fail) & 1u;
-#endif
-#ifdef WF_EXP_NORING
-        ringflag = 0;   // timing experiment only: wrong results
-#endif
     }
     const uint32_t precheck = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
     const uint32_t Pv = running | (precheck << 1) | (((fl >> 7) & 1u) << 2) | (ringflag << 3);
