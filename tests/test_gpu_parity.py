@@ -92,9 +92,10 @@ def test_big_grid_step_matches_oracle(wf, W, H, B):
     T = 70
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
                                auto_reset=(W == 24))
-    assert not env.containment and ("tiled" in env.kernel_name or "cells" in env.kernel_name)
+    assert "tiled" in env.kernel_name or "cells" in env.kernel_name
+    assert env.containment == ("tiled" in env.kernel_name)     # generic shapes: no containment test yet
     env.reset(seed=123)
-    op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=0)
+    op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=int(env.containment))
     planes, envs = O.new_state(B, H, W)
     O.reset(planes, envs, seed=123, params=op)
     gp, ge = env.download()
@@ -121,7 +122,51 @@ def test_big_grid_step_matches_oracle(wf, W, H, B):
 
 def test_big_grid_containment_is_refused_not_ignored(wf):
     with pytest.raises(Exception):
-        wf.BatchedForestFire(4, size=64, containment=True)
+        wf.BatchedForestFire(4, size=11, containment=True)      # generic thread-per-cell family
+
+
+def _circle_actions(ge, W, H, rng):
+    """Scripted policy (host side, test only): walk clockwise around the grid centre."""
+    x, y = ge["x"].astype(int), ge["y"].astype(int)
+    mx, my = W // 2, H // 2
+    a = np.empty(len(x), dtype=np.int8)
+    for i in range(len(x)):
+        if x[i] >= mx and y[i] > my:
+            opts = (1, 3)
+        elif x[i] > mx and y[i] <= my:
+            opts = (1, 2)
+        elif x[i] <= mx and y[i] < my:
+            opts = (0, 2)
+        else:
+            opts = (0, 3)
+        a[i] = opts[rng.integers(2)]
+    return a
+
+
+@pytest.mark.parametrize("W,H", [(24, 24), (32, 20), (14, 14)])
+def test_containment_rewards_with_circling_agents(wf, W, H):
+    """Agents that dig a ring around the fire: the +1000 containment reward (get_reward's A* part,
+    environment.py:345-377) must appear exactly when and where the oracle pays it - tiled family
+    (flood kernel + per-row board test) and wave family alike."""
+    B, T = 96, 150
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=2, containment=True)
+    env.reset(seed=77)
+    op = O.default_params(containment=1)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=77, params=op)
+    rng = np.random.default_rng(5)
+    paid = 0
+    for t in range(T):
+        a = _circle_actions(envs, W, H, rng)
+        _, r, d, _ = env.step(a)
+        ro, do = O.step(planes, envs, a, op)
+        gp, ge = env.download()
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        paid += int((ro == 1000.0).sum())
+    assert paid > B // 4, f"only {paid} containment rewards: the scenario does not exercise the test"
+    env.close()
 
 
 def test_fused_steps_equal_single_steps(wf):

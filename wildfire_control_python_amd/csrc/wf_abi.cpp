@@ -191,8 +191,9 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
     // the wave kernels address the planes with 32-bit byte offsets
     if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;
-    // the containment test (get_reward's A* part) is only built for the wave family so far
-    if (fam != WF_FAM_WAVE && pp.containment) return WF_ERR_UNSUPPORTED;
+    // the containment test (get_reward's A* part) is built for the wave and tiled families
+    if (fam == WF_FAM_CELLS && pp.containment) return WF_ERR_UNSUPPORTED;
+    if (fam == WF_FAM_TILED && pp.containment && H > 1024) return WF_ERR_UNSUPPORTED;   // boards live in LDS (64 KiB)
     if (fam != WF_FAM_WAVE && (unsigned long long)H * W > 0xFFFFull * 0xFFFFull) return WF_ERR_UNSUPPORTED;
 
     int ndev = 0;
@@ -230,12 +231,13 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
             if ((e = hipMemsetAsync(c->d_acc, 0, (size_t)batch * 8, c->stream)) != hipSuccess) break;
         }
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
-        if ((e = hipMalloc((void **)&c->reach, (size_t)batch * 4 * sizeof(u64))) != hipSuccess) break;
+        const size_t reach_words = fam == WF_FAM_WAVE ? (size_t)batch * 4 : (size_t)batch * H * 4;
+        if ((e = hipMalloc((void **)&c->reach, reach_words * sizeof(u64))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_mask, (size_t)batch)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_cold, sizeof(WfCold))) != hipSuccess) break;
         if ((e = hipMemsetAsync(c->planes, 0, cells * 4, c->stream)) != hipSuccess) break;
         if ((e = hipMemsetAsync(c->envs, 0, (size_t)batch * sizeof(wf_env), c->stream)) != hipSuccess) break;
-        if ((e = hipMemsetAsync(c->reach, 0, (size_t)batch * 4 * sizeof(u64), c->stream)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(c->reach, 0, reach_words * sizeof(u64), c->stream)) != hipSuccess) break;
         e = hipStreamSynchronize(c->stream);
     } while (0);
     if (e != hipSuccess) {
@@ -270,10 +272,14 @@ int wf_destroy(wf_ctx *c)
 int wf_set_params(wf_ctx *c, const wf_params *p)
 {
     if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
-    if (c->fam != WF_FAM_WAVE && p->containment) return WF_ERR_UNSUPPORTED;
+    if (c->fam == WF_FAM_CELLS && p->containment) return WF_ERR_UNSUPPORTED;
+    if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->p = *p;
+    // a changed containment switch makes cached reachability boards untrustworthy
+    HIP_TRY(c, wf_launch_invalidate_reach(c->envs, c->batch, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return push_cold(c);
 }
 

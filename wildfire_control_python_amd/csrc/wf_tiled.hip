@@ -25,7 +25,9 @@ namespace {
 
 using namespace wfdev;
 
-enum { MODE_COPY = 0, MODE_STEP = 1, MODE_RESET = 2 };
+enum { MODE_COPY = 0, MODE_STEP = 1, MODE_RESET = 2, MODE_MASK = 3,
+       MODE_PRECHECK = 4,   // containment test may run this step (environment.py:345-346)
+       MODE_FLOOD = 8 };    // the reachability board must be rebuilt before the tick
 constexpr int TR = 16;   // rows per wave strip
 
 // World.reset(), record part (environment.py:186-212): spawn point from the counter-based stream
@@ -60,7 +62,6 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
         if (rs) reset_record(a, e, a.cold->p.seed);   // the cells follow in wf_big_reset_cells
         return;
     }
-    mode[e] = MODE_STEP;
     const uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[e] : 0xffu;
     uint8_t *pe = reinterpret_cast<uint8_t *>(a.planes) + (size_t)e * H * W * 4;
     // ---- Agent.move (environment.py:141-155)
@@ -90,6 +91,31 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
         const uint32_t dies = (fl & 1u) & (((fl >> 3) & 1u) | (ta == WF_FIRE ? 1u : 0u));
         if (dies) fl &= ~(uint32_t)(WF_F_ALIVE | WF_F_VISIBLE);
     }
+    // containment bookkeeping (same exact rule as wf_step_group's phase A): can this dig change
+    // which cells reach the border?  If so the board is rebuilt by wf_big_flood before the tick.
+    uint32_t m = MODE_STEP;
+    if ((a.hot_flags & WF_HOT_CONTAINMENT) && !(fl & (WF_F_BORDER | WF_F_CONTAINED))) {
+        m |= MODE_PRECHECK;
+        bool flood = !(fl & WF_F_REACH_VALID);
+        if (dug && !flood) {
+            const uint32_t xd = qd % W, yd = qd / W;
+            uint32_t ring = 0, bn = 0;
+            const int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
+                if (rx < W && ry < H) {
+                    if (pe[(size_t)(ry * W + rx) * 4] < WF_DIRT) ring |= 1u << r;
+                    if (!(r & 1) && (rx == 0 || ry == 0 || rx == W - 1 || ry == H - 1)) bn |= 1u << r;
+                }
+            }
+            const uint32_t even = ring & 0x55u;
+            const uint32_t eff = ring & 0xAAu & (even << 1) & ((even >> 1) | (even << 7));
+            const bool onb = xd == 0 || yd == 0 || xd == W - 1 || yd == H - 1;
+            flood = (__popc(even) - __popc(eff) >= 2) || (onb && even && !(ring & bn));
+        }
+        if (flood) m |= MODE_FLOOD;
+    }
+    mode[e] = (uint8_t)m;
     if (vis_before) pe[(size_t)qa * 4 + 3] = 0;
     if (dug) pe[(size_t)qd * 4] = (uint8_t)WF_DIRT;
     if (fl & WF_F_VISIBLE) pe[(size_t)(ay * W + ax) * 4 + 3] = 1;
@@ -106,10 +132,11 @@ __global__ __launch_bounds__(256) void wf_big_post(const WfArgs a, const uint8_t
     const uint32_t A = acc[2 * e], healthy = acc[2 * e + 1];
     acc[2 * e] = 0;
     acc[2 * e + 1] = 0;
-    if (mode[e] != MODE_STEP) return;
+    const uint32_t m = mode[e];
+    if ((m & MODE_MASK) != MODE_STEP) return;
     uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
     uint32_t fl = ev.y & 0xffffu;
-    const uint32_t anyfire = A & 1u, bhit = (A >> 1) & 1u;
+    const uint32_t anyfire = A & 1u, bhit = (A >> 1) & 1u, reach_hit = (A >> 2) & 1u;
     const uint32_t upd = (a.update_mask & 1ull) ? 1u : 0u;
     fl |= bhit << 5;                                                                   // set_fire_to :245-246
     if (upd && (!(fl & WF_F_ALIVE) || !anyfire)) fl &= ~(uint32_t)WF_F_RUNNING;        // forest_fire.py:105-106
@@ -117,6 +144,11 @@ __global__ __launch_bounds__(256) void wf_big_post(const WfArgs a, const uint8_t
     double reward = a.default_reward;                                                  // environment.py:390
     if (!anyfire) reward = a.contained_bonus * ((double)healthy / (double)((uint32_t)a.H * (uint32_t)a.W));   // :384-387
     if (!(fl & WF_F_ALIVE)) reward = a.death_penalty;                                  // :380-381
+    // containment (environment.py:345-377): no burning cell is connected to a passable border cell
+    if ((m & MODE_PRECHECK) && anyfire && !bhit && !reach_hit) {
+        fl |= WF_F_CONTAINED;                                                          // :361-367
+        reward = a.contained_bonus;
+    }
     ev.y = fl;
     *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
     if (a.reward) a.reward[e] = reward;
@@ -147,8 +179,12 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const bool has_rows = r0 < H;
     const bool active = lane < LW;
     const uint32_t ign = (uint32_t)a.ignite_count;
-    const bool step = (mode[e] == MODE_STEP) && (a.update_mask & 1ull);
-    const bool reduce = mode[e] == MODE_STEP;
+    const uint32_t md = mode[e];
+    const bool step = ((md & MODE_MASK) == MODE_STEP) && (a.update_mask & 1ull);
+    const bool reduce = (md & MODE_MASK) == MODE_STEP;
+    const bool reach_test = reduce && (md & MODE_PRECHECK);
+    const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4] in this kernel's mask layout
+    uint32_t reach_hit = 0;
     // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
     uint4 *dst = reinterpret_cast<uint4 *>(a.planes_out) + (size_t)e * H * LW + lane;
@@ -252,6 +288,12 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
                 GR[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
             }
         }
+        if (reach_test) {   // does a burning cell sit on a border-connected cell?
+            typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+            typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
+            const u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
+            reach_hit |= ((FIRE[0] & rb.x) | (FIRE[1] & rb.y) | (FIRE[2] & rb.z) | (FIRE[3] & rb.w)) ? 1u : 0u;
+        }
         if (reduce) {
             anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
             healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
@@ -264,10 +306,66 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     }
     bhit |= ((ign_x0 & 1ull) | (ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
     if (reduce && lane == 0) {
-        const uint32_t A = anyfire | (bhit << 1);
+        const uint32_t A = anyfire | (bhit << 1) | (reach_hit << 2);
         if (A) atomicOr(&acc[2 * e], A);
         if (healthy) atomicAdd(&acc[2 * e + 1], healthy);
     }
+}
+
+// ---------------------------------------------------------------------------- flood
+// Border-reachability board of one environment (tiled family): bit l of word [r][j] = cell
+// (row r, x = 4l+j) is 4-connected to a passable border cell through passable cells.  One
+// workgroup per environment, boards resident in LDS, monotone in-place relaxation until
+// nothing changes.  Environments not flagged MODE_FLOOD cost one load.
+__global__ __launch_bounds__(256) void wf_big_flood(const WfArgs a, const uint8_t *mode)
+{
+    extern __shared__ u64 lds[];                     // [H*4] pass, [H*4] reach
+    __shared__ uint32_t changed;
+    const uint32_t e = blockIdx.x;
+    if (!(mode[e] & MODE_FLOOD)) return;
+    const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2, words = H * 4u;
+    u64 *pass = lds, *reach = lds + words;
+    const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+    // passable masks, one row per wave iteration
+    for (uint32_t r = wv; r < H; r += 4u) {
+        uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+        if (lane < LW) c = src[r * LW];
+        const u64 p0 = __ballot((c.x & 0xffu) < WF_DIRT), p1 = __ballot((c.y & 0xffu) < WF_DIRT);
+        const u64 p2 = __ballot((c.z & 0xffu) < WF_DIRT), p3 = __ballot((c.w & 0xffu) < WF_DIRT);
+        if (lane == 0) {
+            const bool edge = r == 0 || r == H - 1;
+            const u64 P[4] = { p0, p1, p2, p3 };
+            for (int j = 0; j < 4; ++j) {
+                pass[r * 4 + j] = P[j];
+                // seeds: passable border cells (first/last row; x == 0 -> word 0 bit 0; x == W-1 -> word 3 bit LW-1)
+                const u64 bm = edge ? ~0ull : (j == 0 ? 1ull : (j == 3 ? (1ull << (LW - 1)) : 0ull));
+                reach[r * 4 + j] = P[j] & bm;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < 4u * (H + W) * 4u; ++it) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        bool ch = false;
+        for (uint32_t k = threadIdx.x; k < words; k += 256u) {
+            const uint32_t r = k >> 2, j = k & 3u;
+            const u64 cur = reach[k];
+            u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);
+            nb |= j > 0 ? reach[k - 1] : (reach[k + 3] << 1);
+            nb |= j < 3 ? reach[k + 1] : (reach[k - 3] >> 1);
+            const u64 nw = cur | (nb & pass[k]);
+            if (nw != cur) { reach[k] = nw; ch = true; }
+        }
+        if (ch) changed = 1;
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    u64 *out = a.reach + (size_t)e * words;
+    for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = reach[k];
+    if (threadIdx.x == 0) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
 }
 
 // ---------------------------------------------------------------------------- generic step
@@ -281,7 +379,7 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
         const uint32_t e = (uint32_t)(i / cells), q = (uint32_t)(i % cells), x = q % W, y = q / W;
         const uint32_t *se = a.planes + (size_t)e * cells;
         uint32_t c = se[q];
-        const uint32_t m = mode[e];
+        const uint32_t m = mode[e] & MODE_MASK;
         if (m == MODE_STEP && (a.update_mask & 1ull)) {
             auto still = [&](uint32_t v) -> uint32_t { return ((v & 0xffu) == WF_FIRE && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
             const uint32_t t = c & 0xffu;
@@ -383,6 +481,10 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     if (a.hot_flags & WF_HOT_AUTO_RESET) {
         hipError_t e = launch_reset_cells(a, mode, MODE_RESET, auto_seed, s);
         if (e != hipSuccess) return e;
+    }
+    if (fam == WF_FAM_TILED && (a.hot_flags & WF_HOT_CONTAINMENT)) {
+        const size_t lds_bytes = (size_t)a.H * 4 * 8 * 2;
+        hipLaunchKernelGGL(wf_big_flood, dim3((unsigned)a.batch), dim3(256), lds_bytes, s, a, (const uint8_t *)mode);
     }
     if (fam == WF_FAM_TILED) {
         const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
