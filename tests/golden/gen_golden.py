@@ -104,7 +104,7 @@ class Recorder:
         self.c = 0.54 * 0.3 * (0 + 1) ** (-1)  # environment.py:286-287 with wind (0,0)
         self.rows = {k: [] for k in ("planes", "agent", "reward", "done", "obs",
                                      "fab", "border_len", "action")}
-        self.init_planes, self.init_agent, self.init_world, self.ep_start = [], [], [], []
+        self.init_planes, self.init_agent, self.init_world, self.ep_start, self.seeds = [], [], [], [], []
 
     def _seqsum(self, n):
         t = 0.0
@@ -141,7 +141,8 @@ class Recorder:
             return [int(a.x), int(a.y), 1, int(a.digging), int(a.dead)]
         return [-1, -1, 0, 0, 1]
 
-    def begin(self):
+    def begin(self, seed=-1):
+        self.seeds.append(seed)
         self.ep_start.append(len(self.rows["action"]))
         self.init_planes.append(self._planes())
         self.init_agent.append(self._agent())
@@ -169,6 +170,7 @@ class Recorder:
             init_planes=np.asarray(self.init_planes, dtype=np.int8),
             init_agent=np.asarray(self.init_agent, dtype=np.int16),
             init_world=np.asarray(self.init_world, dtype=np.int32),   # [fire_at_border, len(border_points)]
+            seeds=np.asarray(self.seeds, dtype=np.int64),             # np.random.seed/random.seed before reset (-1: n/a)
             action=np.asarray(r["action"], dtype=np.int8),
             planes=np.asarray(r["planes"], dtype=np.int8),
             agent=np.asarray(r["agent"], dtype=np.int16),
@@ -291,6 +293,26 @@ def run_size(size):
             a = int(rng.integers(0, 4)) if ep % 2 else NOOP
             _, _, done = rec.step(a)
     rec.save(out("multifire"))
+
+    # 6. rivers (reset_map environment.py:69-95): water is neither burnable nor traversable
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(5000 + size)
+    constants.METADATA["make_rivers"] = True
+    ep, seed = 0, 500
+    while ep < 10:
+        reset(seed)
+        seed += 1
+        fx, fy = size // 2, size // 2
+        if sim.W.env[fx, fy, layer["fire_mobility"]] == np.inf:
+            continue        # river drawn through the fire cell: fire type with infinite mobility, not representable
+        rec.begin(seed - 1)
+        done = False
+        while not done:
+            a = int(rng.integers(0, 4)) if ep % 2 == 0 else circling_policy(sim, rng)
+            _, _, done = rec.step(a)
+        ep += 1
+    constants.METADATA["make_rivers"] = False
+    rec.save(out("river"))
 
 
 def main():

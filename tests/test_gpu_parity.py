@@ -354,6 +354,23 @@ def test_adapter_replays_reference_noop_episode(wf):
         sim.close()
 
 
+def test_adapter_rivers_match_reference_draw_for_draw(wf):
+    """make_rivers=True: seeded reset reproduces the reference's river AND spawn point
+    (reset_map environment.py:69-95 consumes the numpy stream before get_agent_location)."""
+    import random
+    for size in (10, 14):
+        ep = Episodes([f for f in fixture_files(size) if f.endswith("_river.npz")][0])
+        sim = wf.ForestFire(size=size, metadata={"make_rivers": True})
+        for i, seed in enumerate(ep.d["seeds"][:6]):
+            np.random.seed(int(seed))
+            random.seed(int(seed))
+            sim.reset()
+            planes, envs = sim._b.download()
+            np.testing.assert_array_equal(planes[0], ep.init_planes[i], err_msg=f"size {size} seed {seed}")
+            assert (envs["x"][0], envs["y"][0]) == tuple(ep.d["init_agent"][i, :2])
+        sim.close()
+
+
 def test_adapter_string_and_int_actions(wf):
     sim = wf.ForestFire(size=10)
     np.random.seed(5)

@@ -60,8 +60,6 @@ class BatchedForestFire:
             # environment.py:188-190: direction-dependent addends summed in Python set order;
             # the reference itself is not bit-reproducible there - out of parity scope.
             raise NotImplementedError("only wind vector (0, 0) has an exact integer restatement")
-        if self.METADATA["make_rivers"]:
-            raise NotImplementedError("make_rivers: upload planes with water cells instead")
         self.wind_speed, self.wind_vector = wind[0], tuple(wind[1])
 
         p = N.default_params()
@@ -161,6 +159,8 @@ class BatchedForestFire:
     def reset(self, mask=None, seed=None):
         """World.reset() (environment.py:186-212) on the device for every env (or the
         masked ones), spawn points from the counter-based stream.  Returns the state."""
+        if self.METADATA["make_rivers"]:
+            raise NotImplementedError("make_rivers is only built for reset_host() (numpy stream, as the reference)")
         if seed is None:
             seed = self.seed + 0x9E3779B9 * self._reset_count
         self._reset_count += 1
@@ -184,6 +184,9 @@ class BatchedForestFire:
         planes[:, fy, fx, N.P_HEAT] = N.HEAT_FORCED
         envs = np.zeros(B, dtype=N.ENV_DTYPE)
         for b in range(B):
+            if self.METADATA["make_rivers"]:
+                self._make_river(planes[b], rng)          # drawn BEFORE the spawn point, as reset_map does
+                planes[b, fy, fx, N.P_TYPE] = N.FIRE       # set_fire_to retypes the centre afterwards
             sx, sy = spawns[b] if spawns is not None else get_agent_location(W, H, rng)
             planes[b, sy, sx, N.P_AGENT] = 1                               # Agent.__init__ :108-113
             planes[b, sy, sx, N.P_TYPE] = N.DIRT
@@ -192,6 +195,29 @@ class BatchedForestFire:
         self.upload(planes, envs)
         self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
         return self.get_state()
+
+    def _make_river(self, p, rng):
+        """The reference's river generator (reset_map, environment.py:69-95), draw for draw on
+        numpy's legacy stream: a water cell per row from a start near the top, drifting one
+        column left or right.  p: int8 (H, W, 4) planes of one environment."""
+        W, H = self.width, self.height
+        d = [1, 2, 3]
+        fx, fy = get_fire_location(W, H)
+        river_x = rng.choice(list(range(W)))
+        river_y = rng.choice(d)
+        while river_y < (H - rng.choice(d)):
+            p[river_y, river_x, N.P_TYPE] = N.WATER                       # :81 (numpy wraps a -1 index; so do we)
+            new_y = river_y + 1
+            new_x = river_x + rng.choice([1, -1])
+            # `not a <= x < b and not at_fire`: a chained comparison draws `b` only when a <= x holds
+            while True:
+                ok = rng.choice(d) <= new_x
+                if ok:
+                    ok = new_x < (W - rng.choice(d))
+                if ok or (new_x, new_y) == (fx, fy):
+                    break
+                new_x = river_x + rng.choice([1, -1])
+            river_x, river_y = new_x, new_y
 
     # ------------------------------------------------------------------------ step
     def _update_mask(self, n_steps):
