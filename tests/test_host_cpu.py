@@ -184,3 +184,16 @@ def test_learner_targets_follow_the_reference_rule():
             exps = r[i] if done[i] else r[i] + 0.999 * qn[i, ap[i]]
             assert torch.isclose(y[i, a[i]], exp) and torch.isclose(ys[i, a[i]], exps)
         assert net(s).shape == (6, 4)
+
+
+def test_oracle_is_clean_under_asan_ubsan(tmp_path):
+    """GPU sanitizers are unavailable on the pool; the CPU oracle (the checker everything
+    else is compared with) runs under AddressSanitizer + UBSan."""
+    exe = str(tmp_path / "asan_driver")
+    src = os.path.join(REPO, "oracle")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(src, "asan_driver.c"), os.path.join(src, "wf_oracle.c"), "-I", src,
+                           "-o", exe, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and "oracle clean" in out.stdout, out.stderr[-2000:]
