@@ -108,12 +108,16 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    shared_card = world > ndev                 # rehearsal: more ranks than GPUs (ranks share cards, gloo)
+    local = local % ndev
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL (backend "nccl") needs one GPU per rank; it only carries the barrier + one max-reduce
+        dist.init_process_group("gloo" if shared_card else "nccl", rank=rank, world_size=world)
     n_gpus = world
 
     from wildfire_control_python_amd import make_shard
@@ -134,6 +138,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -203,7 +208,7 @@ def main():
         host_api = {"cell_updates_per_s": cells * 29 / th, "us_per_step": th / 29 * 1e6,
                     "note": "wf_step(): H2D actions + launch + D2H reward/done + stream sync per step"}
 
-    t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=("cpu" if shared_card else dev))
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0].item()), float(t[1].item())
