@@ -280,6 +280,55 @@ def test_auto_reset_matches_oracle_reset(wf):
     env.close()
 
 
+def test_split_launch_equals_single_launch_and_oracle(wf, monkeypatch):
+    """Batches >= 16384 on the context's own streams are stepped as two halves on two streams.
+    The split must be invisible: bit-identical to one launch (WF_NO_SPLIT=1) and to the oracle,
+    including auto-resets in the second half (the stream is keyed by the env's context index)."""
+    B, S, T = 16384 + 192, 14, 70          # ragged: the halves are 8320 and 8256 environments
+    kw = dict(size=S, seed=77, auto_reset=True, fuel_range=(3, 9))
+    a_env = wf.BatchedForestFire(B, **kw)
+    b_env = wf.BatchedForestFire(B, **kw)
+    a_env.reset(seed=77)
+    b_env.reset(seed=77)
+    op = O.default_params(fuel_lo=3, fuel_hi=9)
+    idx = np.concatenate([np.arange(0, B, 97), np.arange(B - 40, B)])
+    p0, e0 = a_env.download()
+    rng = np.random.default_rng(9)
+    # the oracle replays a sample under the sample's own global ids: one single-env oracle state each
+    samples = []
+    for i in idx:
+        samples.append([np.ascontiguousarray(p0[i:i + 1]), np.ascontiguousarray(_envs(e0[i:i + 1])).astype(O.ENV_DTYPE), op])
+    resets = 0
+    for t in range(T):
+        a = rng.integers(0, 5, size=B).astype(np.int8)
+        monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+        obs_a, r_a, d_a, _ = a_env.step(a)
+        monkeypatch.setenv("WF_NO_SPLIT", "1")
+        obs_b, r_b, d_b, _ = b_env.step(a)
+        np.testing.assert_array_equal(obs_a, obs_b, err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(r_a, r_b, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d_a, d_b, err_msg=f"done t={t}")
+        for k, i in enumerate(idx):
+            pl, en, op_i = samples[k]
+            stopped = (en["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(pl, en, a[i:i + 1], op_i)
+            if stopped.any():
+                O.reset(pl, en, seed=77, mask=stopped, env_id0=int(i), params=op)
+                ro[:], do[:] = 0.0, 0
+                resets += 1
+            assert r_a[i] == ro[0] and bool(d_a[i]) == bool(do[0]), (t, i)
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    pa, ea = a_env.download()
+    pb, eb = b_env.download()
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ea, eb)
+    for k, i in enumerate(idx):
+        np.testing.assert_array_equal(pa[i], samples[k][0][0], err_msg=f"env {i}")
+    assert resets > len(idx)
+    a_env.close()
+    b_env.close()
+
+
 def test_frozen_after_done_and_reset_mask(wf):
     B = 64
     env = wf.BatchedForestFire(B, size=10, fuel_range=(2, 4))

@@ -10,6 +10,8 @@
 
 #include "wf_internal.h"
 
+constexpr int WF_MAX_SIDE = 3;
+
 struct wf_ctx {
     int device = 0;
     int batch = 0, H = 0, W = 0;
@@ -19,6 +21,14 @@ struct wf_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Split launches: with the context's OWN streams a single step is issued as two independent
+    // halves of the batch on two streams, so that one half's latency-bound prologue overlaps the
+    // other half's compute (environments never interact).  Joined by events before anything else.
+    hipStream_t side[WF_MAX_SIDE] = {};
+    hipEvent_t ev_side[WF_MAX_SIDE] = {}, ev_fork = nullptr;
+    int n_parts = 2;                  // launches per step (WF_SPLIT overrides, 1 = never split)
+    bool side_pending = false;        // work enqueued on `side` that `stream` has not waited for yet
+    bool main_touched = true;         // non-step work enqueued on `stream` since the last fork
     // device state
     uint32_t *planes = nullptr;       // (batch, H*W) dwords
     uint32_t *planes_alt = nullptr;   // tiled path ping-pong
@@ -111,6 +121,26 @@ WfArgs base_args(const wf_ctx *c)
     a.contained_bonus = c->p.contained_bonus;
     return a;
 }
+
+// make `stream` wait for everything issued on the side stream (no host sync)
+int join_side(wf_ctx *c)
+{
+    if (c->side_pending) {         // recorded lazily: an event per step would serialise the side queues
+        for (int i = 0; i < c->n_parts - 1; ++i) {
+            HIP_TRY(c, hipEventRecord(c->ev_side[i], c->side[i]));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[i], 0));
+        }
+        c->side_pending = false;
+    }
+    c->main_touched = true;
+    return WF_OK;
+}
+
+#define JOIN(c)                              \
+    do {                                     \
+        int _rc = join_side(c);              \
+        if (_rc != WF_OK) return _rc;        \
+    } while (0)
 
 // (re)publish the rarely needed parameters to the device
 int push_cold(wf_ctx *c)
@@ -221,6 +251,13 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         c->own_stream = true;
         if ((e = hipEventCreate(&c->ev0)) != hipSuccess) break;
         if ((e = hipEventCreate(&c->ev1)) != hipSuccess) break;
+        if (const char *sp = getenv("WF_SPLIT")) c->n_parts = atoi(sp) < 1 ? 1 : atoi(sp) > WF_MAX_SIDE + 1 ? WF_MAX_SIDE + 1 : atoi(sp);
+        for (int i = 0; i < c->n_parts - 1 && e == hipSuccess; ++i) {
+            if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) break;
+            e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) break;
+        if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) break;
         const size_t cells = (size_t)batch * H * W;
         if ((e = hipMalloc((void **)&c->planes, cells * 4)) != hipSuccess) break;
         if (fam != WF_FAM_WAVE) {
@@ -257,6 +294,8 @@ int wf_destroy(wf_ctx *c)
 {
     if (!c) return WF_ERR_ARG;
     (void)hipSetDevice(c->device);
+    for (hipStream_t sd : c->side)
+        if (sd) (void)hipStreamSynchronize(sd);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_actions, c->d_reward,
                      c->d_done, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc };
@@ -264,6 +303,11 @@ int wf_destroy(wf_ctx *c)
         if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t ev : c->ev_side)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipStream_t sd : c->side)
+        if (sd) (void)hipStreamDestroy(sd);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return WF_OK;
@@ -275,6 +319,7 @@ int wf_set_params(wf_ctx *c, const wf_params *p)
     if (c->fam == WF_FAM_CELLS && p->containment) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->p = *p;
     // a changed containment switch makes cached reachability boards untrustworthy
@@ -287,6 +332,7 @@ int wf_set_stream(wf_ctx *c, void *hip_stream)
 {
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
@@ -298,6 +344,7 @@ int wf_upload(wf_ctx *c, const int8_t *planes, const wf_env *envs)
 {
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     const size_t cells = (size_t)c->batch * c->H * c->W;
     if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, cells * 4, hipMemcpyHostToDevice, c->stream));
     if (envs) HIP_TRY(c, hipMemcpyAsync(c->envs, envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyHostToDevice, c->stream));
@@ -310,6 +357,7 @@ int wf_download(wf_ctx *c, int8_t *planes, wf_env *envs)
 {
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     const size_t cells = (size_t)c->batch * c->H * c->W;
     if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, cells * 4, hipMemcpyDeviceToHost, c->stream));
     if (envs) HIP_TRY(c, hipMemcpyAsync(envs, c->envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyDeviceToHost, c->stream));
@@ -321,6 +369,7 @@ int wf_reset_device(wf_ctx *c, const uint8_t *d_mask, uint64_t seed)
 {
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     WfArgs a = base_args(c);
     a.mask = d_mask;
     a.reset_seed = seed;
@@ -359,9 +408,43 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
         a.done = d_done;
         a.n_steps = n_steps;
         a.update_mask = update_mask;
-        HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
+        const bool split = c->own_stream && c->n_parts > 1 && n_steps == 1 && c->batch >= 8192 * c->n_parts &&
+                           !getenv("WF_NO_SPLIT");
+        if (!split) {
+            JOIN(c);
+            HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
+            return WF_OK;
+        }
+        // independent parts of the batch on separate streams (inputs must be complete when this is
+        // called: the context's own streams are not ordered with the caller's streams)
+        const size_t cells = (size_t)c->H * c->W;
+        if (c->main_touched) {         // the sides must see earlier reset / upload / get_state work of `stream`
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            for (int i = 0; i < c->n_parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+            c->main_touched = false;
+        }
+        const int per = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+        if (a.group <= 0) a.group = wf_pick_group((int)cells, c->num_cus, c->batch);   // as for the whole batch
+        for (int i = 0; i < c->n_parts; ++i) {
+            const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
+            if (lo >= hi) break;
+            WfArgs ai = a;
+            ai.batch = hi - lo;
+            ai.env_base = (uint32_t)lo;
+            ai.planes = a.planes + (size_t)lo * cells;
+            ai.planes_out = ai.planes;
+            ai.envs = a.envs + lo;
+            ai.reach = a.reach + (size_t)lo * 4;
+            if (a.actions) ai.actions = a.actions + lo;
+            if (a.reward) ai.reward = a.reward + lo;
+            if (a.done) ai.done = a.done + lo;
+            if (a.obs) ai.obs = a.obs + (size_t)lo * cells * 3;
+            HIP_TRY(c, wf_launch_step(c->fam, ai, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
+        }
+        c->side_pending = true;
         return WF_OK;
     }
+    JOIN(c);
     // big-grid families: one launch sequence per step, source planes -> destination planes
     for (int st = 0; st < n_steps; ++st) {
         WfArgs a = base_args(c);
@@ -391,12 +474,15 @@ int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_m
     int rc = ensure_staging(c, n_steps);
     if (rc != WF_OK) return rc;
     const size_t n = (size_t)n_steps * (size_t)c->batch;
+    HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     if (actions) HIP_TRY(c, hipMemcpyAsync(c->d_actions, actions, n, hipMemcpyHostToDevice, c->stream));
     const size_t nobs = (size_t)c->batch * c->H * c->W * 3;
     if (obs && !c->d_obs) HIP_TRY(c, hipMalloc((void **)&c->d_obs, nobs));
     rc = wf_step_obs_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask,
                             reward ? c->d_reward : nullptr, done ? c->d_done : nullptr, obs ? c->d_obs : nullptr);
     if (rc != WF_OK) return rc;
+    JOIN(c);
     if (obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));
     if (reward) HIP_TRY(c, hipMemcpyAsync(reward, c->d_reward, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (done) HIP_TRY(c, hipMemcpyAsync(done, c->d_done, n, hipMemcpyDeviceToHost, c->stream));
@@ -408,6 +494,7 @@ int wf_get_state_device(wf_ctx *c, int8_t *d_obs)
 {
     if (!c || !d_obs) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     HIP_TRY(c, wf_launch_get_state(c->planes, d_obs, c->batch, c->H, c->W, c->stream));
     return WF_OK;
 }
@@ -429,6 +516,7 @@ int wf_sync(wf_ctx *c)
 {
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return WF_OK;
 }
@@ -440,6 +528,7 @@ int wf_timer_start(wf_ctx *c)
 {
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     return WF_OK;
 }
@@ -448,6 +537,7 @@ int wf_timer_stop(wf_ctx *c, float *elapsed_ms)
 {
     if (!c || !elapsed_ms) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);                          // the timed region ends when BOTH halves are done
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));

@@ -45,7 +45,7 @@ struct WfArgs {
     int32_t ignite_count;
     int32_t hot_flags;       // WF_HOT_*
     int32_t group;           // single-step group kernel: environments per wave
-    int32_t pad0;
+    uint32_t env_base;       // index of this launch's env 0 inside the context (split launches)
     double default_reward, death_penalty, contained_bonus;
 };
 
@@ -55,6 +55,17 @@ enum WfFamily { WF_FAM_NONE = 0, WF_FAM_WAVE = 1, WF_FAM_TILED = 2, WF_FAM_CELLS
 // Returns the family able to serve (H, W), and its name.
 WfFamily wf_pick_family(int H, int W);
 const char *wf_family_name(WfFamily f, int H, int W);
+
+// Single-step group kernel: environments per wave, sized so that every resident wave slot of
+// the chip (32 per CU) gets one group of a `batch`-environment step.
+static inline int wf_pick_group(int cells, int num_cus, long long batch)
+{
+    int G = 1, gmax = 1;
+    while (gmax * 2 <= cells / 4 && gmax < 32) gmax *= 2;        // env-lane k must be a cell-owning lane
+    while (G < gmax && (long long)G * num_cus * 32 < batch) G *= 2;
+    return G;
+}
+
 
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);

@@ -115,7 +115,7 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
     cold_ptr cold = (cold_ptr)(uintptr_t)cold_g;
     const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
     const uint32_t ppm = cold->p.ignite_ppm;
-    const EnvKey key(seed, cold->p.env_id0 + (u64)e, s.episode);
+    const EnvKey key(seed, cold->p.env_id0 + (u64)e, s.episode);     // e = index inside the context
     const uint32_t r = below(key.draw(0), 3u);                        // radius - 1
     const uint32_t k = below(key.draw(1), (uint32_t)cold->spawn.n[r]);   // point on the circle
     const uint32_t fx = W / 2, fy = H / 2;                            // utility.py:61-64
@@ -734,7 +734,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_group(const WfArgs a)
                     asm volatile("" : "+s"(cold), "+s"(e_pin));
                     cold_ptr cc = (cold_ptr)(uintptr_t)cold;
                     uint32_t t[4], u[4], h[4];
-                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
+                    // the stream is keyed by the env's index in the context, not in this (possibly split) launch
+                    reset_regs<W, H>(cold, cc->p.seed, e_pin + a.env_base, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
                     const uint32_t qs = s.ay * W + s.ax;
                     uint32_t r[4];
 #pragma unroll
@@ -951,10 +952,9 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
         // single step: group layout.  G environments per wave, sized so that every resident wave
         // slot of the chip (32 per CU) gets one group.
         WfArgs g = a;
-        int G = 1, gmax = 1;
-        while (gmax * 2 <= (W * H) / 4 && gmax < 32) gmax *= 2;   // env-lane k must be a cell-owning lane
-        while (G < gmax && (long long)G * num_cus * 32 < a.batch) G *= 2;
-        if (a.group > 0) G = a.group < gmax ? a.group : gmax;     // experiment override (WF_GROUP)
+        int G = wf_pick_group(W * H, num_cus, a.batch);
+        const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
+        if (a.group > 0) G = a.group < gmax ? a.group : gmax;     // split launches / experiment override (WF_GROUP)
         g.group = G;
         const int waves = (a.batch + G - 1) / G;
         hipLaunchKernelGGL((wf_step_group<W, H>), dim3((waves + 3) / 4), dim3(256), 0, s, g);
