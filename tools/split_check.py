@@ -11,9 +11,13 @@ acts = torch.from_numpy(np.random.default_rng(0).integers(0, 4, size=(K, B)).ast
 rew = torch.empty((1, B), dtype=torch.float64, device=dev)
 done = torch.empty((1, B), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-combos = [(1, 0), (2, 0), (3, 0), (2, 4), (2, 0), (1, 0)]
-for parts, group in combos:
+combos = [(1, 0, 0), (1, 0, 1), (2, 0, 0), (2, 0, 1), (2, 16, 1), (3, 0, 1), (3, 16, 1), (2, 0, 1), (2, 0, 0)]
+for parts, group, shared in combos:
     os.environ["WF_SPLIT"] = str(parts)
+    if shared:
+        os.environ["WF_SHARED"] = "1"
+    else:
+        os.environ.pop("WF_SHARED", None)
     if group:
         os.environ["WF_GROUP"] = str(group)
     else:
@@ -26,5 +30,5 @@ for parts, group in combos:
     for s in range(K):
         env.step_device(acts[s], 1, rew, done, update_mask=1)
     ms = env.timer_stop()
-    print(f"parts={parts} group={group or 'auto'} us_per_step={ms * 1e3 / K:.2f} cells/s={B * S * S * K / (ms * 1e-3):.4g}", flush=True)
+    print(f"parts={parts} group={group or 'auto'} shared={shared} us_per_step={ms * 1e3 / K:.2f} cells/s={B * S * S * K / (ms * 1e-3):.4g}", flush=True)
     env.close()
