@@ -62,7 +62,8 @@ enum {
     WF_F_RUNNING     = 16,   /* World.RUNNING                           forest_fire.py:105-106 */
     WF_F_BORDER      = 32,   /* World.fire_at_border                    environment.py:245-246 */
     WF_F_CONTAINED   = 64,   /* containment bonus already paid (border deque empty, :361-367)  */
-    WF_F_REACH_VALID = 128   /* internal: the context's border-reachability bitboard is current */
+    WF_F_REACH_VALID = 128,  /* internal: the context's border-reachability bitboard is current */
+    WF_F_REACH_ROWS  = 256   /* internal: the same, for the rows-layout copy of the bitboard      */
 };
 
 typedef struct wf_env {

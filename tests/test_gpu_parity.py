@@ -14,7 +14,7 @@ from tests.golden_util import Episodes, fixture_files
 
 pytestmark = pytest.mark.gpu
 
-VIS = np.uint16(~np.uint16(128))  # drop WF_F_REACH_VALID (internal cache flag) before comparing
+VIS = np.uint16(~np.uint16(128 | 256))  # drop WF_F_REACH_VALID / _ROWS (internal cache flags) before comparing
 
 
 @pytest.fixture(scope="module")
@@ -166,6 +166,57 @@ def test_containment_rewards_with_circling_agents(wf, W, H):
         np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
         paid += int((ro == 1000.0).sum())
     assert paid > B // 4, f"only {paid} containment rewards: the scenario does not exercise the test"
+    env.close()
+
+
+# The single-step path of the 14x14 grid has four kernels behind it, picked by batch size: the group
+# layout (one environment per wave iteration) and the rows layout (two per iteration), each with
+# private or workgroup-shared agent phases.  Force each one, ragged groups included.
+KERNEL_VARIANTS = {
+    "group-g1": {"WF_NO_ROWS": "1", "WF_GROUP": "1"},
+    "group-g4": {"WF_NO_ROWS": "1", "WF_GROUP": "4"},
+    "group-shared": {"WF_NO_ROWS": "1", "WF_GROUP": "8", "WF_SHARED": "1"},
+    "rows-g2": {"WF_GROUP": "2"},
+    "rows-g6-ragged": {"WF_GROUP": "6"},
+    "rows-g8": {"WF_GROUP": "8"},
+    "rows-shared-g8": {"WF_GROUP": "8", "WF_SHARED": "1"},
+    "rows-shared-g16": {"WF_GROUP": "16", "WF_SHARED": "1"},
+}
+
+
+@pytest.mark.parametrize("variant", list(KERNEL_VARIANTS))
+def test_single_step_kernel_variants_match_oracle(wf, monkeypatch, variant):
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in KERNEL_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    B, S, T = 4096 + 37, 14, 90            # ragged last group / last workgroup
+    env = wf.BatchedForestFire(B, size=S, seed=11, auto_reset=True, containment=True, fuel_range=(4, 12))
+    env.reset(seed=11)
+    op = O.default_params(containment=1, fuel_lo=4, fuel_hi=12)
+    planes, envs = O.new_state(B, S, S)
+    O.reset(planes, envs, seed=11, params=op)
+    rng = np.random.default_rng(3)
+    paid = resets = 0
+    half = B // 2
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        a[:half] = _circle_actions(envs[:half], S, S, rng)       # diggers that close rings: floods + containment
+        obs, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op)
+        if stopped.any():
+            O.reset(planes, envs, seed=11, mask=stopped, params=op)
+            ro[stopped], do[stopped] = 0.0, 0
+            resets += int(stopped.sum())
+        gp, ge = env.download()
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        paid += int((ro == 1000.0).sum())
+    assert paid > 50 and resets > B, (paid, resets)
     env.close()
 
 

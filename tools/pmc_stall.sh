@@ -11,5 +11,5 @@ for pass in 1 2; do
   eval pmc=\$p$pass
   rm -rf gpurun_out/stall_${tag}_$pass
   rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/stall_${tag}_$pass -- python3 bench.py --steps 10 --warmup 2 --fused 0 --no-cpu-baseline > gpurun_out/stall_${tag}_$pass.log 2>&1
-  python tools/pmc_summary.py gpurun_out/stall_${tag}_$pass | grep -A9 "wf_step_group"
+  python tools/pmc_summary.py gpurun_out/stall_${tag}_$pass | grep -A9 "wf_step_"
 done

@@ -103,6 +103,7 @@ WfArgs base_args(const wf_ctx *c)
     a.planes_out = c->planes_alt ? c->planes_alt : c->planes;
     a.envs = c->envs;
     a.reach = c->reach;
+    a.reach_rows = c->fam == WF_FAM_WAVE ? c->reach + (size_t)c->batch * 4 : nullptr;
     a.cold = c->d_cold;
     a.batch = c->batch;
     a.H = c->H;
@@ -268,7 +269,8 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
             if ((e = hipMemsetAsync(c->d_acc, 0, (size_t)batch * 8, c->stream)) != hipSuccess) break;
         }
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
-        const size_t reach_words = fam == WF_FAM_WAVE ? (size_t)batch * 4 : (size_t)batch * H * 4;
+        // wave family: (batch,4) boards of the 4-cells-per-lane kernels + as much again for the rows layout
+        const size_t reach_words = fam == WF_FAM_WAVE ? (size_t)batch * 8 + 64 : (size_t)batch * H * 4;
         if ((e = hipMalloc((void **)&c->reach, reach_words * sizeof(u64))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_mask, (size_t)batch)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_cold, sizeof(WfCold))) != hipSuccess) break;

@@ -32,7 +32,8 @@ struct WfArgs {
     uint32_t *planes;        // (batch, H*W) one dword per cell
     uint32_t *planes_out;    // tiled path: ping-pong target (== planes for the wave path)
     wf_env *envs;            // (batch)
-    u64 *reach;              // (batch, 4) border-reachability bitboards (wave path)
+    u64 *reach;              // (batch, 4) border-reachability bitboards (wave path), pointer of this launch's env 0
+    u64 *reach_rows;         // rows-layout boards of the whole CONTEXT (indexed by context env index / EPW)
     const int8_t *actions;   // (n_steps, batch) or nullptr
     double *reward;          // (n_steps, batch) or nullptr
     uint8_t *done;           // (n_steps, batch) or nullptr
