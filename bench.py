@@ -157,6 +157,19 @@ def main():
     wall = time.perf_counter() - t0
     done_frac = float(d_done.float().mean().item())
 
+    # the same steps issued as ONE launch per step (the library's two-stream split of large batches
+    # switched off): this is the figure rocprofv3's per-kernel average duration can be compared with
+    single_ms = None
+    if env.step_launches > 1:
+        os.environ["WF_NO_SPLIT"] = "1"
+        n_s = min(K, 100)
+        env.step_device(d_act[0], 1, d_rew, d_done, update_mask=1)
+        env.timer_start()
+        for s in range(n_s):
+            env.step_device(d_act[Wm + s], 1, d_rew, d_done, update_mask=1)
+        single_ms = env.timer_stop() / n_s
+        del os.environ["WF_NO_SPLIT"]
+
     # extra: fused steps per launch (grid stays in registers between ticks)
     fused = None
     if args.fused > 1:
@@ -178,7 +191,7 @@ def main():
     # extra: step + observation.  Fused (the step kernel writes World.get_state() itself) against
     # the same step followed by the stand-alone observation kernel.
     obs_extra = None
-    if "group" in env.kernel_name:
+    if env.step_kernel.startswith(("wf_step_group", "wf_step_rows")):
         d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
         torch.cuda.synchronize()
         n_o = min(K, 100)
@@ -238,13 +251,20 @@ def main():
                        "parallelism": f"env-shard x{world}, no collective",
                        "kernel": env.kernel_name},
             "env_steps_per_s": value / (S * S),
+            # one step = `launches_per_step` concurrent launches of `kernel` on separate streams, each over an
+            # equal share of the batch; achieved = algorithmic bytes of the whole step / HIP-event time per step
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, S),
-                         "kernel": (f"wf_step_group<{S},{S}>" if "group" in env.kernel_name else env.kernel_name.split(" ")[0]),
+                         "kernel": env.step_kernel, "launches_per_step": env.step_launches,
                          "launch_us": launch_ms * 1e3,
-                         "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells},
+                         "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells,
+                         "note": ("launch_us/bytes are per STEP (all concurrent launches of it); "
+                                  "single_launch = the same step as one launch, comparable with rocprofv3 kernel stats")},
             "done_frac_last_step": done_frac,
         }
+        if single_ms is not None:
+            a1 = BYTES_PER_CELL_UPDATE * cells / (single_ms * 1e-3) / 1e9
+            out["roofline"]["single_launch"] = {"launch_us": single_ms * 1e3, "achieved": a1, "frac": a1 / HBM_PEAK_GBS}
         if fused:
             out["fused"] = fused
         if obs_extra:

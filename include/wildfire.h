@@ -160,8 +160,12 @@ void *wf_envs_device(wf_ctx *ctx);     /* wf_env[batch]                     */
 int wf_timer_start(wf_ctx *ctx);
 int wf_timer_stop(wf_ctx *ctx, float *elapsed_ms);   /* synchronises */
 
-/* Introspection: name of the kernel family serving this context's grid shape. */
+/* Introspection: name of the kernel family serving this context's grid shape; symbol of the kernel
+ * behind a single step (n_steps == 1) of this context, and how many concurrent launches of it one
+ * step is (large batches on the context's own streams are stepped as two half-batch launches). */
 const char *wf_kernel_name(const wf_ctx *ctx);
+const char *wf_step_kernel_name(const wf_ctx *ctx);
+int wf_step_launches(const wf_ctx *ctx);
 
 #ifdef __cplusplus
 }

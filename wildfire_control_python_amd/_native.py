@@ -21,7 +21,7 @@ P_TYPE, P_FUEL, P_HEAT, P_AGENT = 0, 1, 2, 3
 GRASS, FIRE, BURNT, DIRT, WATER = 0, 1, 2, 3, 4
 HEAT_FORCED = 25
 F_ALIVE, F_VISIBLE, F_DIGGING, F_DEAD = 1, 2, 4, 8
-F_RUNNING, F_BORDER, F_CONTAINED, F_REACH_VALID = 16, 32, 64, 128
+F_RUNNING, F_BORDER, F_CONTAINED, F_REACH_VALID, F_REACH_ROWS = 16, 32, 64, 128, 256
 
 WF_OK = 0
 ABI_VERSION = 1
@@ -71,6 +71,8 @@ SYMBOLS = [
     ("wf_timer_start", _i, [_vp]),
     ("wf_timer_stop", _i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     ("wf_kernel_name", ctypes.c_char_p, [_vp]),
+    ("wf_step_kernel_name", ctypes.c_char_p, [_vp]),
+    ("wf_step_launches", _i, [_vp]),
 ]
 
 _lib = None

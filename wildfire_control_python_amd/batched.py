@@ -91,6 +91,8 @@ class BatchedForestFire:
             raise N.WildfireError(rc, f"wf_create(batch={batch}, H={self.height}, W={self.width})")
         self._h = h
         self.kernel_name = self._lib.wf_kernel_name(self._h).decode()
+        self.step_kernel = self._lib.wf_step_kernel_name(self._h).decode()      # behind a single step
+        self.step_launches = int(self._lib.wf_step_launches(self._h))          # concurrent launches per step
 
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc, where):

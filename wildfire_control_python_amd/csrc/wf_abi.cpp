@@ -143,6 +143,13 @@ int join_side(wf_ctx *c)
         if (_rc != WF_OK) return _rc;        \
     } while (0)
 
+// A single step of a large batch on the context's OWN streams goes out as n_parts concurrent launches.
+bool splits(const wf_ctx *c, int n_steps)
+{
+    return c->fam == WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && n_steps == 1 && c->batch >= 8192 * c->n_parts &&
+           !getenv("WF_NO_SPLIT");
+}
+
 // (re)publish the rarely needed parameters to the device
 int push_cold(wf_ctx *c)
 {
@@ -410,8 +417,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
         a.done = d_done;
         a.n_steps = n_steps;
         a.update_mask = update_mask;
-        const bool split = c->own_stream && c->n_parts > 1 && n_steps == 1 && c->batch >= 8192 * c->n_parts &&
-                           !getenv("WF_NO_SPLIT");
+        const bool split = splits(c, n_steps);
         if (!split) {
             JOIN(c);
             HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
@@ -549,6 +555,22 @@ int wf_timer_stop(wf_ctx *c, float *elapsed_ms)
 const char *wf_kernel_name(const wf_ctx *c)
 {
     return c ? wf_family_name(c->fam, c->H, c->W) : "none";
+}
+
+const char *wf_step_kernel_name(const wf_ctx *c)
+{
+    if (!c) return "none";
+    WfArgs a = base_args(c);
+    if (splits(c, 1)) {
+        if (a.group <= 0) a.group = wf_pick_group(c->H * c->W, c->num_cus, c->batch);
+        a.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+    }
+    return wf_single_step_kernel(c->fam, a, c->num_cus);
+}
+
+int wf_step_launches(const wf_ctx *c)
+{
+    return c ? (splits(c, 1) ? c->n_parts : 1) : 0;
 }
 
 }  // extern "C"

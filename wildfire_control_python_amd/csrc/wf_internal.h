@@ -69,6 +69,7 @@ static inline int wf_pick_group(int cells, int num_cus, long long batch)
 
 
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
+const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus);
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 // big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out

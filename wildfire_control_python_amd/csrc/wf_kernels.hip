@@ -1513,6 +1513,37 @@ __global__ __launch_bounds__(256) void wf_invalidate_reach_kernel(wf_env *envs, 
     if (i < batch) envs[i].flags &= (uint16_t)~(WF_F_REACH_VALID | WF_F_REACH_ROWS);
 }
 
+// Which kernel serves a single step (n_steps == 1) of `a.batch` environments.
+//   G     environments per wave, sized so that every resident wave slot of the chip (32 per CU) gets
+//         one group (a.group > 0: fixed by a split launch or the WF_GROUP experiment override)
+//   rows  layout with several environments per wave iteration, where the shape has an instantiation
+//         (WF_NO_ROWS=1 keeps the 4-cells-per-lane group layout)
+//   shared (WF_SHARED=1, opt-in) a workgroup shares the agent phases A and C over 64 environments:
+//         fewer instructions (-10..-20 %), but the barrier costs as much as it saves once two
+//         half-batch launches overlap (measured 23.3 vs 22.4 us per 65536x14x14 step)
+enum { STEP_GROUP = 0, STEP_GROUP_SHARED = 1, STEP_ROWS = 2, STEP_ROWS_SHARED = 3 };
+struct StepPlan { int G, kind; };
+
+template <int W, int H> struct HasRows { static constexpr bool value = false; static constexpr int S = 1; };
+template <> struct HasRows<14, 14> { static constexpr bool value = true; static constexpr int S = 2; };
+
+template <int W, int H>
+StepPlan plan_single(const WfArgs &a, int num_cus)
+{
+    StepPlan p;
+    p.G = wf_pick_group(W * H, num_cus, a.batch);
+    const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
+    if (a.group > 0) p.G = a.group < gmax ? a.group : gmax;
+    const bool shared = getenv("WF_SHARED") && (p.G == 8 || p.G == 16) && a.batch >= 4096;
+    p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
+    if constexpr (HasRows<W, H>::value) {
+        constexpr int EPW = RG<W, H, HasRows<W, H>::S>::EPW;
+        if (p.G % EPW == 0 && p.G <= 16 && a.env_base % EPW == 0 && !getenv("WF_NO_ROWS"))
+            p.kind = shared ? STEP_ROWS_SHARED : STEP_ROWS;
+    }
+    return p;
+}
+
 template <int W, int H>
 hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
 {
@@ -1525,33 +1556,18 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
     else if (a.n_steps > 1)
         hipLaunchKernelGGL((wf_step_wave<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
     else {
-        // single step: group layout.  G environments per wave, sized so that every resident wave
-        // slot of the chip (32 per CU) gets one group.
+        const StepPlan p = plan_single<W, H>(a, num_cus);
         WfArgs g = a;
-        int G = wf_pick_group(W * H, num_cus, a.batch);
-        const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
-        if (a.group > 0) G = a.group < gmax ? a.group : gmax;     // split launches / experiment override (WF_GROUP)
-        g.group = G;
-        const int waves = (a.batch + G - 1) / G;
-        // shapes with a rows-layout instantiation: several environments per wave iteration
-        if constexpr (W == 14 && H == 14) {
-            constexpr int EPW = RG<W, H, 2>::EPW;
-            if (G % EPW == 0 && G <= 16 && a.env_base % EPW == 0 && !getenv("WF_NO_ROWS")) {
-                if (getenv("WF_SHARED") && (G == 8 || G == 16) && a.batch >= 4096)
-                    hipLaunchKernelGGL((wf_step_rows<W, H, 2, true>), dim3((a.batch + 63) / 64), dim3(64 * (64 / G)), 0, s, g);
-                else
-                    hipLaunchKernelGGL((wf_step_rows<W, H, 2, false>), dim3((waves + 3) / 4), dim3(256), 0, s, g);
-                return hipGetLastError();
-            }
+        g.group = p.G;
+        const int waves = (a.batch + p.G - 1) / p.G;
+        const dim3 grid_private((waves + 3) / 4), grid_shared((a.batch + 63) / 64), block_shared(64 * (64 / p.G));
+        if constexpr (HasRows<W, H>::value) {
+            constexpr int S = HasRows<W, H>::S;
+            if (p.kind == STEP_ROWS) hipLaunchKernelGGL((wf_step_rows<W, H, S, false>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS_SHARED) hipLaunchKernelGGL((wf_step_rows<W, H, S, true>), grid_shared, block_shared, 0, s, g);
         }
-        // optional (WF_SHARED=1): a workgroup shares phases A and C over 64 environments (64/G waves).
-        // Fewer instructions (-10 %), but the barrier costs as much as it saves once two half-batch
-        // launches overlap (measured 23.1 vs 22.5 us per 65536x14x14 step), so it is off by default.
-        const bool shared = (G == 8 || G == 16) && a.batch >= 4096 && getenv("WF_SHARED");
-        if (shared)
-            hipLaunchKernelGGL((wf_step_group<W, H, true>), dim3((a.batch + 63) / 64), dim3(64 * (64 / G)), 0, s, g);
-        else
-            hipLaunchKernelGGL((wf_step_group<W, H, false>), dim3((waves + 3) / 4), dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP) hipLaunchKernelGGL((wf_step_group<W, H, false>), grid_private, dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP_SHARED) hipLaunchKernelGGL((wf_step_group<W, H, true>), grid_shared, block_shared, 0, s, g);
     }
     return hipGetLastError();
 }
@@ -1580,11 +1596,28 @@ WfFamily wf_pick_family(int H, int W)
 const char *wf_family_name(WfFamily f, int, int)
 {
     switch (f) {
-    case WF_FAM_WAVE: return "wf_step_group/wf_step_wave (wave-per-env CA core on ballot bitboards; env logic lane-parallel)";
+    case WF_FAM_WAVE: return "wf_step_rows/wf_step_group/wf_step_wave (whole grids in a wave's registers, CA core on ballot bitboards; env logic lane-parallel)";
     case WF_FAM_TILED: return "wf_step_tiled (16-row strips per wave, ballot row masks, LDS-staged strip halos)";
     case WF_FAM_CELLS: return "wf_step_cells (generic thread-per-cell)";
     default: return "none";
     }
+}
+
+// symbol of the kernel that would serve a single step of `a` (introspection for bench / profiles)
+const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus)
+{
+    static thread_local char buf[64];
+    if (fam == WF_FAM_TILED) return "wf_step_tiled";
+    if (fam == WF_FAM_CELLS) return "wf_step_cells";
+    StepPlan p = { 0, -1 };
+    int S = 1;
+#define X(w, h) if (a.W == w && a.H == h) { p = plan_single<w, h>(a, num_cus); S = HasRows<w, h>::S; }
+    WF_WAVE_SHAPES(X)
+#undef X
+    if (p.kind < 0) return "none";
+    if (p.kind >= STEP_ROWS) snprintf(buf, sizeof buf, "wf_step_rows<%d,%d,%d,%s>", a.W, a.H, S, p.kind == STEP_ROWS_SHARED ? "true" : "false");
+    else snprintf(buf, sizeof buf, "wf_step_group<%d,%d,%s>", a.W, a.H, p.kind == STEP_GROUP_SHARED ? "true" : "false");
+    return buf;
 }
 
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus)
