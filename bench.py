@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--size", type=int, default=14)
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the extra fused measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline loop only: no fused / observation / host-API / single-launch legs (profiling passes)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--ignite-ppm", type=int, default=0, help="extra pre-ignited cells per million at reset (config 4)")
@@ -160,7 +162,7 @@ def main():
     # the same steps issued as ONE launch per step (the library's two-stream split of large batches
     # switched off): this is the figure rocprofv3's per-kernel average duration can be compared with
     single_ms = None
-    if env.step_launches > 1:
+    if env.step_launches > 1 and not args.no_extras:
         os.environ["WF_NO_SPLIT"] = "1"
         n_s = min(K, 100)
         env.step_device(d_act[0], 1, d_rew, d_done, update_mask=1)
@@ -172,7 +174,7 @@ def main():
 
     # extra: fused steps per launch (grid stays in registers between ticks)
     fused = None
-    if args.fused > 1:
+    if args.fused > 1 and not args.no_extras:
         F = args.fused
         reps = max(1, K // F)
         d_act_f = torch.from_numpy(make_actions(F, lo, lo + B, args.seed + 1)).to(dev)
@@ -191,7 +193,7 @@ def main():
     # extra: step + observation.  Fused (the step kernel writes World.get_state() itself) against
     # the same step followed by the stand-alone observation kernel.
     obs_extra = None
-    if env.step_kernel.startswith(("wf_step_group", "wf_step_rows")):
+    if env.step_kernel.startswith(("wf_step_group", "wf_step_rows")) and not args.no_extras:
         d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
         torch.cuda.synchronize()
         n_o = min(K, 100)
@@ -211,7 +213,7 @@ def main():
     # extra: the synchronous host-buffer entry point (numpy actions in, reward/done out): PCIe and
     # host synchronisation included.  Reported for completeness; it is never `value`.
     host_api = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         a_np = make_actions(30, lo, lo + B, args.seed + 2)
         env.step_many(a_np[0])
         th = time.perf_counter()
