@@ -131,8 +131,12 @@ int wf_reset_device(wf_ctx *ctx, const uint8_t *d_mask, uint64_t seed);
  *   done uint8 (n_steps, batch); reward/done may be NULL.
  * update() runs every params-independent a_speed-th step: the caller passes
  * update_mask, bit s = run update() in step s (all ones for a_speed = 1; n_steps <= 64).
- * wf_step is synchronous with host buffers; wf_step_device is asynchronous on the
- * context's stream with device buffers. */
+ * wf_step is synchronous with host buffers; wf_step_device is asynchronous with device buffers.
+ * Ordering of the *_device calls: with a caller stream (wf_set_stream) everything is enqueued on that
+ * stream, in order.  With the context's OWN streams (the default) the calls of one context are ordered
+ * among themselves, the device buffers handed in must be complete when the call is made, and results
+ * are complete after wf_sync / wf_timer_stop (a large single step is issued as two concurrent
+ * half-batch launches on two internal streams; every other call joins them first). */
 int wf_step(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mask,
             double *reward, uint8_t *done);
 int wf_step_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
