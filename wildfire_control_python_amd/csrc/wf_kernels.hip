@@ -255,6 +255,9 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 // single-step kernel counts the connected components exactly and refines the border case
 // (see wf_step_group).
 
+#ifndef WF_STORE_WAIT
+#define WF_STORE_WAIT 1   // 0: private-phase kernels skip the wait for phase A byte stores (no measurable gain: 22.4-22.7 us either way)
+#endif
 #ifndef WF_LB
 #define WF_LB 6   // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -1203,7 +1206,10 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, 8) void wf_step_rows(const WfAr
             sS[S_R][ai] = 0;
         }
         if (SHARED && lane == 0) sS[S_CNT][0] = 0;
-        __builtin_amdgcn_s_waitcnt(0);                       // the byte stores have landed
+        // Other waves of the workgroup read the touched bytes back: the stores must have landed.  The wave's
+        // own later loads need no wait: a wave's vector memory instructions reach its L1 in program order
+        // (wavefront-scope fences are no-ops in the AMDGPU memory model), the fence below only stops the compiler.
+        if (SHARED || WF_STORE_WAIT) __builtin_amdgcn_s_waitcnt(0);
     }
     if constexpr (SHARED) __syncthreads();
     else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
