@@ -65,29 +65,44 @@ def make_actions(steps, lo, hi, seed):
     return out
 
 
-def cpu_baseline(size, seed, seconds):
-    """The oracle (plain-C restatement of the reference step, 1 thread) on a bounded
-    sample of the same workload: 2048 envs, same fuel law / action law / auto-reset."""
+def _cpu_worker(args):
+    size, seed, seconds, tid, B = args
     from oracle import oracle as O
-    B = 2048
     p = O.default_params(fuel_lo=10, fuel_hi=40)
     planes, envs = O.new_state(B, size, size)
-    O.reset(planes, envs, seed=seed, params=p)
-    rng = np.random.default_rng(seed)
+    O.reset(planes, envs, seed=seed, env_id0=tid * B, params=p)
+    rng = np.random.default_rng([seed, tid])
     steps, t0 = 0, time.perf_counter()
     while True:
         a = rng.integers(0, 4, size=B).astype(np.int8)
         _, done = O.step(planes, envs, a, p)
         if done.any():
-            O.reset(planes, envs, seed=seed, mask=done, params=p)
+            O.reset(planes, envs, seed=seed, mask=done, env_id0=tid * B, params=p)
         steps += 1
         el = time.perf_counter() - t0
         if el >= seconds:
-            break
-    return {"value": B * size * size * steps / el, "unit": "cell-updates/s", "cores": 1,
+            return steps, el
+
+
+def cpu_baseline(size, seed, seconds):
+    """The oracle (plain-C restatement of the reference step) on a bounded sample of the same workload:
+    2048 envs per worker process, same fuel law / action law / auto-reset, one worker per core of this
+    process's CPU share (capped at 16).  Must run BEFORE this process touches the GPU (it forks)."""
+    import multiprocessing as mp
+    B = 2048
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(16, cores))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(size, seed, seconds, t, B) for t in range(cores)])
+    value = sum(B * size * size * st / el for st, el in res)
+    return {"value": value, "unit": "cell-updates/s", "cores": cores,
             "kind": "port",
-            "sample": f"{B} envs x {size}x{size}, {steps} steps in {el:.1f}s, oracle/wf_oracle.c single thread "
-                      f"(reference Python path: 5.5e5 cell-updates/s on 1 core, BASELINE.md section 2)"}
+            "sample": f"{cores} processes x {B} envs x {size}x{size}, {sum(st for st, _ in res)} steps in {seconds:.0f}s each, "
+                      f"oracle/wf_oracle.c ({value / cores:.3g} cell-updates/s per core; reference Python path: 5.5e5 "
+                      f"cell-updates/s on 1 core, BASELINE.md section 2)"}
 
 
 def measured_traffic(batch, size):
@@ -107,6 +122,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.size, args.seed, args.cpu_seconds)      # forks: before anything touches the GPU
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -273,8 +291,8 @@ def main():
             out["step_plus_observation"] = obs_extra
         if host_api:
             out["host_buffer_api"] = host_api
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, args.seed, args.cpu_seconds)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
