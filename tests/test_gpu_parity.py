@@ -120,6 +120,50 @@ def test_big_grid_step_matches_oracle(wf, W, H, B):
     env.close()
 
 
+def test_big_grid_split_equals_single_launch_and_oracle(wf, monkeypatch):
+    """Big-grid jobs (>= 8 Mi cells) on the context's own streams run as two shares of the batch on two
+    streams; the result must not depend on it (reset streams are keyed by the context-level env index)."""
+    W = H = 64
+    B, T = 2100, 24
+    kw = dict(width=W, height=H, seed=9, auto_reset=True, containment=True, fuel_range=(2, 5), ignite_ppm=30000)
+    a_env, b_env = wf.BatchedForestFire(B, **kw), wf.BatchedForestFire(B, **kw)
+    assert a_env.step_launches == 2
+    a_env.reset(seed=9)
+    b_env.reset(seed=9)
+    op = O.default_params(containment=1, fuel_lo=2, fuel_hi=5, ignite_ppm=30000)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=9, params=op)
+    rng = np.random.default_rng(1)
+    resets = 0
+    for t in range(T):
+        a = rng.integers(0, 5, size=B).astype(np.int8)
+        monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+        obs_a, r_a, d_a, _ = a_env.step(a)
+        monkeypatch.setenv("WF_NO_SPLIT", "1")
+        obs_b, r_b, d_b, _ = b_env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op)
+        if stopped.any():
+            O.reset(planes, envs, seed=9, mask=stopped, params=op)
+            ro[stopped], do[stopped] = 0.0, 0
+            resets += int(stopped.sum())
+        np.testing.assert_array_equal(r_a, r_b, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d_a, d_b, err_msg=f"done t={t}")
+        np.testing.assert_array_equal(obs_a, obs_b, err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(r_a, ro, err_msg=f"reward vs oracle t={t}")
+        np.testing.assert_array_equal(d_a, do.astype(bool), err_msg=f"done vs oracle t={t}")
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    pa, ea = a_env.download()
+    pb, eb = b_env.download()
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ea, eb)
+    np.testing.assert_array_equal(pa, planes)
+    np.testing.assert_array_equal(_envs(ea), envs)
+    assert resets > 0
+    a_env.close()
+    b_env.close()
+
+
 def test_big_grid_containment_is_refused_not_ignored(wf):
     with pytest.raises(Exception):
         wf.BatchedForestFire(4, size=11, containment=True)      # generic thread-per-cell family

@@ -150,6 +150,12 @@ bool splits(const wf_ctx *c, int n_steps)
            !getenv("WF_NO_SPLIT");
 }
 
+bool splits_big(const wf_ctx *c)
+{
+    return c->fam != WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && c->batch >= 2 * c->n_parts &&
+           (size_t)c->batch * c->H * c->W >= ((size_t)8 << 20) && !getenv("WF_NO_SPLIT");
+}
+
 // (re)publish the rarely needed parameters to the device
 int push_cold(wf_ctx *c)
 {
@@ -452,19 +458,46 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
         c->side_pending = true;
         return WF_OK;
     }
-    JOIN(c);
-    // big-grid families: one launch sequence per step, source planes -> destination planes
+    // big-grid families: one launch sequence per step, source planes -> destination planes.  Large jobs on
+    // the context's own streams run as n_parts independent shares of the batch on separate streams: the
+    // small lanes = environments kernels of one share overlap the streaming kernel of the other.
+    const size_t cells = (size_t)c->H * c->W;
+    const bool split = splits_big(c);
+    const int parts = split ? c->n_parts : 1;
+    const int per = (c->batch + parts - 1) / parts;
+    if (split) {
+        if (c->main_touched) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            for (int i = 0; i < parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+            c->main_touched = false;
+        }
+    } else {
+        JOIN(c);
+    }
     for (int st = 0; st < n_steps; ++st) {
-        WfArgs a = base_args(c);
         const size_t off = (size_t)st * (size_t)c->batch;
-        a.actions = d_actions ? d_actions + off : nullptr;
-        a.reward = d_reward ? d_reward + off : nullptr;
-        a.done = d_done ? d_done + off : nullptr;
-        a.n_steps = 1;
-        a.update_mask = (update_mask >> st) & 1ull;
-        HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode, c->d_acc, c->p.seed, c->stream));
+        for (int i = 0; i < parts; ++i) {
+            const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
+            if (lo >= hi) break;
+            WfArgs a = base_args(c);
+            a.batch = hi - lo;
+            a.env_base = (uint32_t)lo;
+            a.planes += (size_t)lo * cells;
+            a.planes_out += (size_t)lo * cells;
+            a.envs += lo;
+            a.reach += (size_t)lo * c->H * 4;
+            a.actions = d_actions ? d_actions + off + lo : nullptr;
+            a.reward = d_reward ? d_reward + off + lo : nullptr;
+            a.done = d_done ? d_done + off + lo : nullptr;
+            a.n_steps = 1;
+            a.update_mask = (update_mask >> st) & 1ull;
+            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, c->p.seed,
+                                          i == 0 ? c->stream : c->side[i - 1]));
+        }
         uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t;   // ping-pong
     }
+    if (split) c->side_pending = true;
+    if (d_obs) JOIN(c);
     if (d_obs) HIP_TRY(c, wf_launch_get_state(c->planes, d_obs, c->batch, c->H, c->W, c->stream));
     return WF_OK;
 }
@@ -570,7 +603,7 @@ const char *wf_step_kernel_name(const wf_ctx *c)
 
 int wf_step_launches(const wf_ctx *c)
 {
-    return c ? (splits(c, 1) ? c->n_parts : 1) : 0;
+    return c ? ((splits(c, 1) || splits_big(c)) ? c->n_parts : 1) : 0;
 }
 
 }  // extern "C"

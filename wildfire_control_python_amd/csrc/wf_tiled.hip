@@ -35,7 +35,7 @@ __device__ __forceinline__ void reset_record(const WfArgs &a, uint32_t e, u64 se
 {
     const WfCold *cold = a.cold;
     uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
-    const EnvKey key(seed, cold->p.env_id0 + (u64)e, ev.z);
+    const EnvKey key(seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z);
     const uint32_t r = below(key.draw(0), 3u);
     const uint32_t k = below(key.draw(1), (uint32_t)cold->spawn.n[r]);
     const uint32_t sx = (uint32_t)a.W / 2u + (int)cold->spawn.dx[r][k], sy = (uint32_t)a.H / 2u + (int)cold->spawn.dy[r][k];
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const 
     const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
     const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1), ppm = cold->p.ignite_ppm;
     const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec
-    const EnvKey key(seed, cold->p.env_id0 + (u64)e, ev.z - 1u);
+    const EnvKey key(seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
     const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
     uint32_t *pe = a.planes + (size_t)e * cells;
     bool border_fire = false;
