@@ -37,8 +37,8 @@ BYTES_PER_CELL_UPDATE = 8      # 4 int8 planes read + 4 written
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
     ap.add_argument("--size", type=int, default=14)
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the extra fused measurement (0 = skip)")
@@ -182,7 +182,7 @@ def main():
     single_ms = None
     if env.step_launches > 1 and not args.no_extras:
         os.environ["WF_NO_SPLIT"] = "1"
-        n_s = min(K, 100)
+        n_s = min(K, 300)
         env.step_device(d_act[0], 1, d_rew, d_done, update_mask=1)
         env.timer_start()
         for s in range(n_s):
@@ -194,7 +194,7 @@ def main():
     fused = None
     if args.fused > 1 and not args.no_extras:
         F = args.fused
-        reps = max(1, K // F)
+        reps = max(1, min(K, 320) // F)
         d_act_f = torch.from_numpy(make_actions(F, lo, lo + B, args.seed + 1)).to(dev)
         d_rew_f = torch.empty((F, B), dtype=torch.float64, device=dev)
         d_done_f = torch.empty((F, B), dtype=torch.uint8, device=dev)
@@ -214,7 +214,7 @@ def main():
     if env.step_kernel.startswith(("wf_step_group", "wf_step_rows")) and not args.no_extras:
         d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
         torch.cuda.synchronize()
-        n_o = min(K, 100)
+        n_o = min(K, 300)
         env.step_device(d_act[0], 1, d_rew, d_done, update_mask=1, d_obs=d_obs)
         env.timer_start()
         for s in range(n_o):
