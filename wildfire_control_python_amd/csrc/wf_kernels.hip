@@ -255,6 +255,9 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 // single-step kernel counts the connected components exactly and refines the border case
 // (see wf_step_group).
 
+#ifndef WF_LB_ROWS
+#define WF_LB_ROWS 8   // rows kernel: 56 VGPRs, 8 waves per SIMD (fewer resident waves measured slower)
+#endif
 #ifndef WF_STORE_WAIT
 #define WF_STORE_WAIT 1   // 0: private-phase kernels skip the wait for phase A byte stores (no measurable gain: 22.4-22.7 us either way)
 #endif
@@ -1159,7 +1162,7 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
 }
 
 template <int W, int H, int S, bool SHARED>
-__global__ __launch_bounds__(SHARED ? 512 : 256, 8) void wf_step_rows(const WfArgs a)
+__global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(const WfArgs a)
 {
     using R = RG<W, H, S>;
     constexpr int CELLS = W * H, CPL = R::CPL, LPE = R::LPE, PITCH = R::PITCH, EPW = R::EPW;
