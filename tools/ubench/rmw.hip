@@ -76,6 +76,44 @@ __global__ __launch_bounds__(256) void rmw_rows(char *p, unsigned n_env)
     }
 }
 
+// pattern 5: half-row loads as pattern 2, but the stores leave through an LDS transpose as dense 16-byte pieces
+__global__ __launch_bounds__(256) void rmw_rows_lds(char *p, unsigned n_env)
+{
+    constexpr int CPL = 7, LPE = 28, EPW = 2, ENVS_PER_WAVE = 8;
+    __shared__ __attribute__((aligned(16))) unsigned lds[4][EPW * 196 + 8];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wv = threadIdx.x >> 6;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    const unsigned e0 = wave * ENVS_PER_WAVE;
+    const unsigned h = lane / 30u, l = lane % 30u;
+    if (e0 >= n_env || l >= LPE || h >= EPW) return;
+    const unsigned off = h * ENV_BYTES + l * (CPL * 4u);
+    const unsigned cell0 = h * 196u + l * 7u;                  // dword index of this lane's first cell in the pair image
+    const unsigned rank = h * 28u + l;                          // dense index among the 56 working lanes
+    unsigned c[CPL], n[CPL];
+    auto load = [&](unsigned e, unsigned *r) {
+        const char *q = p + (size_t)e * ENV_BYTES + off;
+        const uint4 a = *reinterpret_cast<const uint4 *>(q);
+        const uint3 b = *reinterpret_cast<const uint3 *>(q + 16);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z;
+    };
+    load(e0, n);
+    for (unsigned k = 0; k < ENVS_PER_WAVE; k += EPW) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) c[i] = n[i] + 1u;
+        load(e0 + min(k + EPW, (unsigned)ENVS_PER_WAVE - EPW), n);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) lds[wv][cell0 + i] = c[i];
+        char *q = p + (size_t)(e0 + k) * ENV_BYTES;            // 1568 contiguous bytes = 98 pieces of 16
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(&lds[wv][rank * 4u]);
+        *reinterpret_cast<uint4 *>(q + rank * 16u) = v0;
+        if (rank < 42u) {
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(&lds[wv][(rank + 56u) * 4u]);
+            *reinterpret_cast<uint4 *>(q + (rank + 56u) * 16u) = v1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rmw_flat(uint4 *p, size_t n16)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
@@ -104,6 +142,9 @@ static float run(int pattern, char *buf, size_t n_env, int parts, int iters, hip
             } else if (pattern == 3) {
                 const unsigned waves = (unsigned)(n / 16);
                 hipLaunchKernelGGL((rmw_rows<14, 14, 4, 16>), dim3((waves + 3) / 4), dim3(256), 0, st[q], b, (unsigned)n);
+            } else if (pattern == 5) {
+                const unsigned waves = (unsigned)(n / 8);
+                hipLaunchKernelGGL(rmw_rows_lds, dim3((waves + 3) / 4), dim3(256), 0, st[q], b, (unsigned)n);
             } else if (pattern == 4) {
                 const unsigned waves = (unsigned)(n / 8);
                 hipLaunchKernelGGL((rmw_rows<14, 14, 4, 8>), dim3((waves + 3) / 4), dim3(256), 0, st[q], b, (unsigned)n);
@@ -135,13 +176,13 @@ int main()
         char *buf;
         CHECK(hipMalloc((void **)&buf, n_env * ENV_BYTES));
         CHECK(hipMemset(buf, 0, n_env * ENV_BYTES));
-        for (int pattern = 0; pattern < 5; ++pattern)
+        for (int pattern = 0; pattern < 6; ++pattern)
             for (int parts = 1; parts <= 2; ++parts) {
                 const int iters = n_env > 100000 ? 10 : 300;
                 const float us = run(pattern, buf, n_env, parts, iters, st);
                 const double gbs = 2.0 * n_env * ENV_BYTES / (us * 1e-6) / 1e9;
                 printf("envs=%zu pattern=%s parts=%d  %.2f us/pass  %.0f GB/s (read+write)\n", n_env,
-                       pattern == 0 ? "env-wave" : pattern == 1 ? "flat" : pattern == 2 ? "halfrow-2env" : pattern == 3 ? "row-4env-16" : "row-4env-8", parts, us, gbs);
+                       pattern == 0 ? "env-wave" : pattern == 1 ? "flat" : pattern == 2 ? "halfrow-2env" : pattern == 3 ? "row-4env-16" : pattern == 4 ? "row-4env-8" : "halfrow-lds-store", parts, us, gbs);
                 fflush(stdout);
             }
         CHECK(hipFree(buf));
