@@ -190,7 +190,8 @@ def main():
         single_ms = env.timer_stop() / n_s
         del os.environ["WF_NO_SPLIT"]
 
-    # extra: fused steps per launch (grid stays in registers between ticks)
+    # extra: n steps per API call (step_many).  Small batches run them in ONE launch with the grid in
+    # registers between ticks; large batches as n single-step launches, which is the faster of the two there.
     fused = None
     if args.fused > 1 and not args.no_extras:
         F = args.fused
@@ -205,7 +206,8 @@ def main():
         for _ in range(reps):
             env.step_device(d_act_f, F, d_rew_f, d_done_f, update_mask=(1 << F) - 1)
         f_ms = env.timer_stop()
-        fused = {"steps_per_launch": F, "launches": reps,
+        fused = {"steps_per_call": F, "calls": reps,
+                 "launches_per_call": (F * env.step_launches if env.step_launches > 1 else 1),
                  "cell_updates_per_s_per_gpu": cells * F * reps / (f_ms * 1e-3)}
 
     # extra: step + observation.  Fused (the step kernel writes World.get_state() itself) against
@@ -286,7 +288,7 @@ def main():
             a1 = BYTES_PER_CELL_UPDATE * cells / (single_ms * 1e-3) / 1e9
             out["roofline"]["single_launch"] = {"launch_us": single_ms * 1e3, "achieved": a1, "frac": a1 / HBM_PEAK_GBS}
         if fused:
-            out["fused"] = fused
+            out["steps_per_call"] = fused
         if obs_extra:
             out["step_plus_observation"] = obs_extra
         if host_api:

@@ -1573,7 +1573,13 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
             if (p.kind == STEP_ROWS) hipLaunchKernelGGL((wf_step_rows<W, H, S, false>), grid_private, dim3(256), 0, s, g);
-            if (p.kind == STEP_ROWS_SHARED) hipLaunchKernelGGL((wf_step_rows<W, H, S, true>), grid_shared, block_shared, 0, s, g);
+            if (p.kind == STEP_ROWS_SHARED) {
+                // WF_SHARED=N with N in {2,4,8}: N waves share the agent phases (N*G <= 64 environments per workgroup)
+                int nw = atoi(getenv("WF_SHARED"));
+                if (nw < 2 || nw * p.G > 64) nw = 64 / p.G;
+                const int per_wg = nw * p.G;
+                hipLaunchKernelGGL((wf_step_rows<W, H, S, true>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
+            }
         }
         if (p.kind == STEP_GROUP) hipLaunchKernelGGL((wf_step_group<W, H, false>), grid_private, dim3(256), 0, s, g);
         if (p.kind == STEP_GROUP_SHARED) hipLaunchKernelGGL((wf_step_group<W, H, true>), grid_shared, block_shared, 0, s, g);
