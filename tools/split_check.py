@@ -14,7 +14,7 @@ acts = torch.from_numpy(np.random.default_rng(0).integers(0, 4, size=(K, B)).ast
 rew = torch.empty((1, B), dtype=torch.float64, device=dev)
 done = torch.empty((1, B), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-combos = [(2, 0, 0), (2, 0, 2), (2, 0, 4), (2, 0, 8), (1, 0, 2), (1, 0, 4), (2, 0, 0)]
+combos = [(2, 0, 0), (2, 0, 4), (2, 0, 8), (3, 0, 0), (3, 0, 4), (2, 16, 4), (2, 0, 0)]
 for parts, group, shared in combos:
     os.environ["WF_SPLIT"] = str(parts)
     if shared:

@@ -31,7 +31,8 @@ struct wf_ctx {
     bool main_touched = true;         // non-step work enqueued on `stream` since the last fork
     // device state
     uint32_t *planes = nullptr;       // (batch, H*W) dwords
-    uint32_t *planes_alt = nullptr;   // tiled path ping-pong
+    uint32_t *planes_alt = nullptr;   // generic thread-per-cell family: ping-pong target
+    u64 *d_halo = nullptr;            // tiled family (steps in place): masks of the rows between workgroups
     wf_env *envs = nullptr;
     u64 *reach = nullptr;
     // device staging for the host-buffer entry points (grown on demand)
@@ -275,7 +276,11 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         const size_t cells = (size_t)batch * H * W;
         if ((e = hipMalloc((void **)&c->planes, cells * 4)) != hipSuccess) break;
         if (fam != WF_FAM_WAVE) {
-            if ((e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
+            if (fam == WF_FAM_TILED) {   // in place + 64 B of halo masks per workgroup
+                if ((e = hipMalloc((void **)&c->d_halo, (size_t)batch * wf_tiled_groups(H) * 8 * sizeof(u64))) != hipSuccess) break;
+            } else {
+                if ((e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
+            }
             if ((e = hipMalloc((void **)&c->d_mode, (size_t)batch)) != hipSuccess) break;
             if ((e = hipMalloc((void **)&c->d_acc, (size_t)batch * 8)) != hipSuccess) break;
             if ((e = hipMemsetAsync(c->d_mode, 0, (size_t)batch, c->stream)) != hipSuccess) break;
@@ -313,7 +318,7 @@ int wf_destroy(wf_ctx *c)
         if (sd) (void)hipStreamSynchronize(sd);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_actions, c->d_reward,
-                     c->d_done, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc };
+                     c->d_done, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo };
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -499,10 +504,11 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.done = d_done ? d_done + off + lo : nullptr;
             a.n_steps = 1;
             a.update_mask = (update_mask >> st) & 1ull;
-            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, c->p.seed,
+            u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H) * 8 : nullptr;
+            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, halo, c->p.seed,
                                           i == 0 ? c->stream : c->side[i - 1]));
         }
-        uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t;   // ping-pong
+        if (c->planes_alt) { uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t; }   // ping-pong
     }
     if (split) c->side_pending = true;
     if (d_obs) JOIN(c);

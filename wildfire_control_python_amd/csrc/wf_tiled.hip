@@ -166,7 +166,12 @@ __device__ __forceinline__ void still_masks(const uint4 &r, u64 (&S)[4])
         S[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);
 }
 
-__global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc)
+// outer != nullptr: IN-PLACE mode.  planes_out == planes; the masks of the rows just outside the workgroup
+// (which another workgroup may already have rewritten) come from `outer` (wf_big_halo, written before this
+// launch), environments that are not stepped are not touched at all, and a lane stores its four cells only
+// when one of them changed - most cells do not change in a tick.  outer == nullptr: ping-pong mode, every
+// cell is copied to planes_out.
+__global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer)
 {
     __shared__ u64 halo[4][2][4];                    // [strip][first,last row][component]
     const uint32_t lane = __lane_id();
@@ -183,6 +188,8 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const bool step = ((md & MODE_MASK) == MODE_STEP) && (a.update_mask & 1ull);
     const bool reduce = (md & MODE_MASK) == MODE_STEP;
     const bool reach_test = reduce && (md & MODE_PRECHECK);
+    const bool inplace = outer != nullptr;
+    if (inplace && !reduce) return;                        // frozen / freshly reset environment: nothing to do
     const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4] in this kernel's mask layout
     uint32_t reach_hit = 0;
     // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
@@ -217,6 +224,12 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
                 const u64 v = halo[wv - 1][1][j];
                 Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
             }
+        } else if (inplace) {   // workgroup's outer halo: masks of the ORIGINAL row, saved by wf_big_halo
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 v = outer[(size_t)blockIdx.x * 8 + j];
+                Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+            }
         } else {   // workgroup's outer halo: from global memory
             uint4 up = inert;
             if (active) up = src[(r0 - 1u) * LW];
@@ -228,6 +241,12 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const u64 v = halo[wv + 1][0][j];
+                Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+            }
+        } else if (inplace) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 v = outer[(size_t)blockIdx.x * 8 + 4 + j];
                 Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
             }
         } else {
@@ -298,7 +317,8 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
             anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
             healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
         }
-        if (active) dst[r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
+        if (active && (!inplace || ((c[0] ^ cur.x) | (c[1] ^ cur.y) | (c[2] ^ cur.z) | (c[3] ^ cur.w))))
+            dst[r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Sp[j] = Sc[j]; Sc[j] = Sn[j]; }
         cur = nxt;
@@ -309,6 +329,31 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
         const uint32_t A = anyfire | (bhit << 1) | (reach_hit << 2);
         if (A) atomicOr(&acc[2 * e], A);
         if (healthy) atomicAdd(&acc[2 * e + 1], healthy);
+    }
+}
+
+// ---------------------------------------------------------------------------- outer halos (in-place mode)
+// Still-burning masks of the two rows just outside every workgroup of wf_step_tiled, taken from the state
+// BEFORE the tick: halo[(e*gx + g)*8 + 0..3] = row above workgroup g, +4..7 = row below.  One wave per row.
+__global__ __launch_bounds__(256) void wf_big_halo(const WfArgs a, const uint8_t *mode, u64 *halo)
+{
+    const uint32_t lane = __lane_id();
+    const uint32_t H = (uint32_t)a.H, LW = (uint32_t)a.W >> 2;
+    const uint32_t gx = (H + 4u * TR - 1u) / (4u * TR);
+    const uint32_t task = rfl(blockIdx.x * 4u + (threadIdx.x >> 6));      // (e, g, side)
+    if (task >= (uint32_t)a.batch * gx * 2u) return;
+    const uint32_t side = task & 1u, g = (task >> 1) % gx, e = (task >> 1) / gx;
+    if ((mode[e] & MODE_MASK) != MODE_STEP) return;
+    const uint32_t first = g * 4u * TR, endr = min(first + 4u * TR, H);
+    if (side == 0 ? first == 0 : endr >= H) return;                        // grid edge: no such row
+    const uint32_t r = side == 0 ? first - 1u : endr;
+    uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+    if (lane < LW) c = (reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane)[r * LW];
+    u64 S[4];
+    still_masks(c, S);
+    if (lane == 0) {
+        u64 *o = halo + ((size_t)e * gx + g) * 8 + side * 4u;
+        o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
     }
 }
 
@@ -474,7 +519,9 @@ hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_valu
     return hipGetLastError();
 }
 
-hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 auto_seed, hipStream_t s)
+int wf_tiled_groups(int H) { return (H + 4 * TR - 1) / (4 * TR); }
+
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s)
 {
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_pre, dim3(eb), dim3(256), 0, s, a, mode);
@@ -488,7 +535,11 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     }
     if (fam == WF_FAM_TILED) {
         const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
-        hipLaunchKernelGGL(wf_step_tiled, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc);
+        if (halo && gx > 1) {     // in place: save the masks of the rows between workgroups before anyone rewrites them
+            const unsigned tasks = (unsigned)a.batch * gx * 2u;
+            hipLaunchKernelGGL(wf_big_halo, dim3((tasks + 3) / 4), dim3(256), 0, s, a, (const uint8_t *)mode, halo);
+        }
+        hipLaunchKernelGGL(wf_step_tiled, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc, (const u64 *)halo);
     } else {
         const size_t total = (size_t)a.batch * a.H * a.W;
         size_t blocks = (total + 255) / 256;
