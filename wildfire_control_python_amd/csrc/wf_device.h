@@ -7,6 +7,20 @@ namespace wfdev {
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool lanebit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// d = a + b + (lane's bit of the wave mask): one VALU instruction counts a neighbour set
+__device__ __forceinline__ uint32_t addc(uint32_t a, uint32_t b, u64 carry)
+{
+    uint32_t d;
+    asm("v_addc_co_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(carry) : "vcc");
+    return d;
+}
+__device__ __forceinline__ uint32_t addc0(uint32_t a, u64 carry)
+{
+    uint32_t d;
+    asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(d) : "v"(a), "s"(carry) : "vcc");
+    return d;
+}
+
 // ----------------------------------------------------------------------------
 // counter-based stream (same arithmetic as oracle/wf_oracle.c, written independently)
 // ----------------------------------------------------------------------------

@@ -984,20 +984,6 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
 // ...), never on divergent control flow; per-environment scalars are cut out of the masks with
 // the constant lane sets hm(h).  Phases A and C are those of wf_step_group; the environment
 // registers travel through LDS in both the private and the workgroup-shared variant.
-// d = a + b + (lane's bit of the wave mask): one VALU instruction counts a neighbour set
-__device__ __forceinline__ uint32_t addc(uint32_t a, uint32_t b, u64 carry)
-{
-    uint32_t d;
-    asm("v_addc_co_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(carry) : "vcc");
-    return d;
-}
-__device__ __forceinline__ uint32_t addc0(uint32_t a, u64 carry)
-{
-    uint32_t d;
-    asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(d) : "v"(a), "s"(carry) : "vcc");
-    return d;
-}
-
 constexpr u64 rg_lanes(int W, int H, int S, int kind, int j)
 {
     const int LPE = H * S, PITCH = LPE + S, CPL = W / S, EPW = (64 + S) / PITCH;

@@ -280,17 +280,18 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
-                c[j] += lanebit(F) ? 0xFFFFFF01u : 0u;                         // fuel -= 1, fire -> burnt ...
-                c[j] -= lanebit(Sc[j]) ? 1u : 0u;                              // ... unless still burning
+                // fuel -= 1 and fire -> burnt (+0xFFFFFF01) unless still burning (+0xFFFFFF00): the burn-out
+                // lanes arrive as the carry-in of one add
+                c[j] = addc(c[j], lanebit(F) ? 0xFFFFFF00u : 0u, F & ~Sc[j]);
                 const u64 G = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);   // idle lanes hold inert (dirt) cells
-                // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows
+                // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows; every
+                // neighbour set is counted by one add-with-carry-in
                 const u64 LF = j > 0 ? Sc[(j + 3) & 3] : (Sc[3] << 1);
                 const u64 RT = j < 3 ? Sc[(j + 1) & 3] : (Sc[0] >> 1);
-                const uint32_t cnt = (lanebit(Sp[j]) ? 1u : 0u) + (lanebit(Sn[j]) ? 1u : 0u) +
-                                     (lanebit(LF) ? 1u : 0u) + (lanebit(RT) ? 1u : 0u);
+                const uint32_t cnt = addc0(addc0(addc0(lanebit(Sp[j]) ? 1u : 0u, Sn[j]), LF), RT);
                 const uint32_t room = ign - ((c[j] >> 16) & 0xffu);
                 const u64 IGN = G & __ballot(cnt >= room);                     // apply_heat_from_to :278-294
-                const uint32_t cn = c[j] + (min(cnt, room) << 16) + (lanebit(IGN) ? 1u : 0u);
+                const uint32_t cn = addc(c[j], min(cnt, room) << 16, IGN);     // heat saturates; grass -> fire (+1)
                 c[j] = lanebit(G) ? cn : c[j];
                 anyign |= IGN;
                 if (j == 0) ign_x0 |= IGN;                                      // cells with x == 0 (lane 0)
