@@ -596,6 +596,64 @@ def test_batched_learner_runs_on_the_device_api(wf, algo):
 
 
 # ---------------------------------------------------------------- API edge cases
+@pytest.mark.parametrize("variant", ["rows-g2", "group-g4"])
+def test_upload_and_kernel_switch_invalidate_reach_boards(wf, monkeypatch, variant):
+    """The border-reachability boards are caches in kernel-private layouts.  Editing the planes from the host
+    (a ring of dirt dropped around the fire) and switching between the kernels that keep different copies
+    (single step <-> fused multi-step) must never leave a stale board behind: containment is paid exactly when
+    the oracle's flood pays it."""
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in KERNEL_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    B, S = 96, 14
+    env = wf.BatchedForestFire(B, size=S, seed=4, containment=True, fuel_range=(30, 40))
+    env.reset(seed=4)
+    op = O.default_params(containment=1, fuel_lo=30, fuel_hi=40)
+    planes, envs = O.new_state(B, S, S)
+    O.reset(planes, envs, seed=4, params=op)
+    rng = np.random.default_rng(2)
+    paid = 0
+
+    def both(a):
+        nonlocal paid
+        _, r, d, _ = env.step(a)
+        ro, do = O.step(planes, envs, a, op)
+        np.testing.assert_array_equal(r, ro)
+        np.testing.assert_array_equal(d, do.astype(bool))
+        paid += int((ro == 1000.0).sum())
+
+    for t in range(6):                                     # boards get computed / validated
+        both(rng.integers(0, 4, size=B).astype(np.int8))
+    # host edit: a closed ring of dirt at distance 4 around the centre of every second environment
+    gp, ge = env.download()
+    c = S // 2
+    for e in range(0, B, 2):
+        for k in range(-4, 5):
+            for (yy, xx) in ((c - 4, c + k), (c + 4, c + k), (c + k, c - 4), (c + k, c + 4)):
+                if gp[e, yy, xx, 0] in (0, 2):
+                    gp[e, yy, xx, 0] = 3
+                    planes[e, yy, xx, 0] = 3
+    env.upload(gp, ge)        # records as downloaded: their internal board-valid bits must not survive the upload
+    for t in range(10):
+        both(np.full(B, 5, dtype=np.int8))                 # no-ops: agents inside the ring stay put
+    assert paid >= B // 4, f"{paid}: the uploaded rings should have contained fires"
+    # switch kernels back and forth: 3 fused steps (4-cells-per-lane boards), then single steps again
+    for rep in range(3):
+        a3 = rng.integers(0, 4, size=(3, B)).astype(np.int8)
+        r3, d3 = env.step_many(a3)
+        for k in range(3):
+            ro, do = O.step(planes, envs, a3[k], op)
+            np.testing.assert_array_equal(r3[k], ro)
+            np.testing.assert_array_equal(d3[k], do.astype(bool))
+        for t in range(4):
+            both(rng.integers(0, 4, size=B).astype(np.int8))
+    gp, ge = env.download()
+    np.testing.assert_array_equal(gp, planes)
+    np.testing.assert_array_equal(_envs(ge), envs)
+    env.close()
+
+
 def test_api_edge_cases(wf):
     """Odd batch sizes, NULL optional buffers, 64 fused steps, partial uploads, error codes."""
     import ctypes
