@@ -213,7 +213,7 @@ def test_containment_rewards_with_circling_agents(wf, W, H):
     env.close()
 
 
-# The single-step path of the 14x14 grid has four kernels behind it, picked by batch size: the group
+# The single-step path of the 14x14 and 10x10 grids has four kernels behind it, picked by batch size: the group
 # layout (one environment per wave iteration) and the rows layout (two per iteration), each with
 # private or workgroup-shared agent phases.  Force each one, ragged groups included.
 KERNEL_VARIANTS = {
@@ -228,13 +228,14 @@ KERNEL_VARIANTS = {
 }
 
 
+@pytest.mark.parametrize("S", [14, 10])
 @pytest.mark.parametrize("variant", list(KERNEL_VARIANTS))
-def test_single_step_kernel_variants_match_oracle(wf, monkeypatch, variant):
+def test_single_step_kernel_variants_match_oracle(wf, monkeypatch, variant, S):
     for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED"):
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_VARIANTS[variant].items():
         monkeypatch.setenv(k, v)
-    B, S, T = 4096 + 37, 14, 90            # ragged last group / last workgroup
+    B, T = 4096 + 37, 90                   # ragged last group / last workgroup
     env = wf.BatchedForestFire(B, size=S, seed=11, auto_reset=True, containment=True, fuel_range=(4, 12))
     env.reset(seed=11)
     op = O.default_params(containment=1, fuel_lo=4, fuel_hi=12)

@@ -984,9 +984,13 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
 // ...), never on divergent control flow; per-environment scalars are cut out of the masks with
 // the constant lane sets hm(h).  Phases A and C are those of wf_step_group; the environment
 // registers travel through LDS in both the private and the workgroup-shared variant.
+// environments per wave iteration: as many as fit with S idle lanes between them AND one idle lane above the
+// last one (the carry-out trick of the result extraction needs that lane: top lane index <= 62)
+constexpr int rg_epw(int H, int S) { return (63 + S) / (H * S + S); }
+
 constexpr u64 rg_lanes(int W, int H, int S, int kind, int j)
 {
-    const int LPE = H * S, PITCH = LPE + S, CPL = W / S, EPW = (64 + S) / PITCH;
+    const int LPE = H * S, PITCH = LPE + S, CPL = W / S, EPW = rg_epw(H, S);
     u64 m = 0;
     for (int h = 0; h < EPW; ++h)
         for (int l = 0; l < LPE; ++l) {
@@ -1006,8 +1010,8 @@ template <int W, int H, int S>
 struct RG {
     static_assert(W % S == 0, "a row must split evenly over S lanes");
     static constexpr int CELLS = W * H, CPL = W / S, LPE = H * S, PITCH = LPE + S;
-    static constexpr int EPW = (64 + S) / PITCH;
-    static_assert(LPE < 64 && EPW >= 1, "environment does not fit the wave in this layout");
+    static constexpr int EPW = rg_epw(H, S);
+    static_assert(LPE < 64 && EPW >= 1 && EPW * PITCH - S < 64, "environment does not fit the wave in this layout");
     static constexpr u64 ENV0 = (1ull << LPE) - 1ull;
     static constexpr u64 hm(int h) { return ENV0 << (h * PITCH); }          // lanes of environment h
     static constexpr u64 CELL_LANES = rg_lanes(W, H, S, 0, 0);
@@ -1541,7 +1545,8 @@ enum { STEP_GROUP = 0, STEP_GROUP_SHARED = 1, STEP_ROWS = 2, STEP_ROWS_SHARED = 
 struct StepPlan { int G, kind; };
 
 template <int W, int H> struct HasRows { static constexpr bool value = false; static constexpr int S = 1; };
-template <> struct HasRows<14, 14> { static constexpr bool value = true; static constexpr int S = 2; };
+template <> struct HasRows<14, 14> { static constexpr bool value = true; static constexpr int S = 2; };   // 7 cells/lane, 2 envs/iteration
+template <> struct HasRows<10, 10> { static constexpr bool value = true; static constexpr int S = 2; };   // 5 cells/lane, 2 envs/iteration
 
 template <int W, int H>
 StepPlan plan_single(const WfArgs &a, int num_cus)
