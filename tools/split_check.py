@@ -14,7 +14,7 @@ acts = torch.from_numpy(np.random.default_rng(0).integers(0, 4, size=(K, B)).ast
 rew = torch.empty((1, B), dtype=torch.float64, device=dev)
 done = torch.empty((1, B), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-combos = [(2, 0, 0), (2, 0, 4), (2, 0, 8), (3, 0, 0), (3, 0, 4), (2, 16, 4), (2, 0, 0)]
+combos = [(1, 2, 0), (1, 4, 0), (1, 6, 0), (1, 8, 0), (2, 4, 0), (2, 6, 0), (2, 8, 0), (2, 10, 0), (2, 12, 0)]
 for parts, group, shared in combos:
     os.environ["WF_SPLIT"] = str(parts)
     if shared:
