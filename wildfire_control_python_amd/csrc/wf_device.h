@@ -1,11 +1,24 @@
 // wf_device.h - device helpers shared by the kernel files (wf_kernels.hip, wf_tiled.hip).
 #pragma once
 #include "wf_internal.h"
+#include <utility>
 
 namespace wfdev {
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool lanebit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // d = a + b + (lane's bit of the wave mask): one VALU instruction counts a neighbour set
 __device__ __forceinline__ uint32_t addc(uint32_t a, uint32_t b, u64 carry)

@@ -71,17 +71,6 @@ struct CM {
     static constexpr int DN_SH = (J + W) / 4;
 };
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 // Neighbour masks of a per-component cell set S (bit l of S[j] <-> cell 4l+j).
 template <int W, int H, int J>
 __device__ __forceinline__ u64 nb_up(const u64 (&S)[4]) { return S[CM<W, H, J>::UP_SRC] << CM<W, H, J>::UP_SH; }

@@ -166,11 +166,103 @@ __device__ __forceinline__ void still_masks(const uint4 &r, u64 (&S)[4])
         S[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);
 }
 
-// outer != nullptr: IN-PLACE mode.  planes_out == planes; the masks of the rows just outside the workgroup
-// (which another workgroup may already have rewritten) come from `outer` (wf_big_halo, written before this
-// launch), environments that are not stepped are not touched at all, and a lane stores its four cells only
-// when one of them changed - most cells do not change in a tick.  outer == nullptr: ping-pong mode, every
-// cell is copied to planes_out.
+// The step runs IN PLACE (planes_out == planes).  The masks of the two rows just outside the workgroup - which
+// another workgroup may already have rewritten - come from `outer` (wf_big_halo, written before this launch);
+// environments that are not stepped are not touched at all; a lane stores its four cells only when one of them
+// changed (most cells do not change in a tick).
+//
+// The sweep keeps three rows in flight (cells C[3], still-burning masks M[3]) and is unrolled three times, so
+// that "previous / current / next row" is a renaming of registers instead of 16 moves per row; the per-launch
+// switches (update or not, containment test or not) are template parameters of the sweep.
+struct TiledAcc { uint32_t anyfire, bhit, healthy, reach_hit; u64 ign_x0, ign_xl; };
+
+template <bool STEP, bool REACH>
+__device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, uint32_t ign, bool active, const uint4 &cur,
+                                          const u64 (&Sp)[4], const u64 (&Sc)[4], const u64 (&Sn)[4], const u64 *reach_e,
+                                          uint4 *dst, TiledAcc &A)
+{
+    uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
+    u64 FIRE[4], GR[4];
+    if constexpr (STEP) {
+        u64 anyign = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+            // fuel -= 1 and fire -> burnt (+0xFFFFFF01) unless still burning (+0xFFFFFF00): the burn-out
+            // lanes arrive as the carry-in of one add
+            c[j] = addc(c[j], lanebit(F) ? 0xFFFFFF00u : 0u, F & ~Sc[j]);
+            const u64 G = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);   // idle lanes hold inert (dirt) cells
+            // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows; every
+            // neighbour set is counted by one add-with-carry-in
+            const u64 LF = j > 0 ? Sc[(j + 3) & 3] : (Sc[3] << 1);
+            const u64 RT = j < 3 ? Sc[(j + 1) & 3] : (Sc[0] >> 1);
+            const uint32_t cnt = addc0(addc0(addc0(lanebit(Sp[j]) ? 1u : 0u, Sn[j]), LF), RT);
+            const uint32_t room = ign - ((c[j] >> 16) & 0xffu);
+            const u64 IGN = G & __ballot(cnt >= room);                     // apply_heat_from_to :278-294
+            const uint32_t cn = addc(c[j], min(cnt, room) << 16, IGN);     // heat saturates; grass -> fire (+1)
+            c[j] = lanebit(G) ? cn : c[j];
+            anyign |= IGN;
+            if (j == 0) A.ign_x0 |= IGN;                                    // cells with x == 0 (lane 0)
+            if (j == 3) A.ign_xl |= IGN;                                    // cells with x == W-1 (lane LW-1)
+            FIRE[j] = Sc[j] | IGN;
+            GR[j] = G & ~IGN;
+        }
+        // set_fire_to :245-246: first / last row of the grid are border rows
+        if ((r == 0 || r == H - 1) && anyign) A.bhit = 1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+            GR[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
+        }
+    }
+    if constexpr (REACH) {   // does a burning cell sit on a border-connected cell?
+        typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+        typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
+        const u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
+        A.reach_hit |= ((FIRE[0] & rb.x) | (FIRE[1] & rb.y) | (FIRE[2] & rb.z) | (FIRE[3] & rb.w)) ? 1u : 0u;
+    }
+    A.anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
+    A.healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
+    if constexpr (STEP) {
+        if (active && ((c[0] ^ cur.x) | (c[1] ^ cur.y) | (c[2] ^ cur.z) | (c[3] ^ cur.w)))
+            dst[r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
+    }
+}
+
+template <bool STEP, bool REACH>
+__device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, bool active,
+                                            const uint4 *src, uint4 *dst, const uint4 &first, const u64 (&Sf)[4],
+                                            const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, TiledAcc &A)
+{
+    const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+    uint4 C[3] = { first, inert, inert };
+    u64 M[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { M[0][j] = Sf[j]; M[2][j] = Sabove[j]; M[1][j] = 0; }
+    if (r0 + 1 < r1 && active) C[1] = src[(r0 + 1u) * LW];
+    for (uint32_t r = r0; r < r1; r += 3u) {
+        static_for<3>([&](auto K) {
+            constexpr int k = decltype(K)::value, kn = (k + 1) % 3, kp = (k + 2) % 3;
+            const uint32_t rr = r + (uint32_t)k;
+            if (rr < r1) {
+                // the registers of row rr-1 are free: request row rr+2 into them
+                C[kp] = inert;
+                if (rr + 2 < r1 && active) C[kp] = src[(rr + 2u) * LW];
+                u64 Sn[4];
+                if (rr + 1 < r1) still_masks(C[kn], Sn);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Sn[j] = Sbelow[j];
+                }
+                tiled_row<STEP, REACH>(rr, H, LW, ign, active, C[k], M[kp], M[k], Sn, reach_e, dst, A);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) M[kn][j] = Sn[j];
+            }
+        });
+    }
+}
+
 __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer)
 {
     __shared__ u64 halo[4][2][4];                    // [strip][first,last row][component]
@@ -185,16 +277,13 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const bool active = lane < LW;
     const uint32_t ign = (uint32_t)a.ignite_count;
     const uint32_t md = mode[e];
-    const bool step = ((md & MODE_MASK) == MODE_STEP) && (a.update_mask & 1ull);
-    const bool reduce = (md & MODE_MASK) == MODE_STEP;
-    const bool reach_test = reduce && (md & MODE_PRECHECK);
-    const bool inplace = outer != nullptr;
-    if (inplace && !reduce) return;                        // frozen / freshly reset environment: nothing to do
+    if ((md & MODE_MASK) != MODE_STEP) return;             // frozen / freshly reset environment: nothing to do
+    const bool step = (a.update_mask & 1ull) != 0;
+    const bool reach_test = (md & MODE_PRECHECK) != 0;
     const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4] in this kernel's mask layout
-    uint32_t reach_hit = 0;
     // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
-    uint4 *dst = reinterpret_cast<uint4 *>(a.planes_out) + (size_t)e * H * LW + lane;
+    uint4 *dst = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane;
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
 
     // ---- prologue: masks of the strip's first and last row -> LDS
@@ -215,121 +304,38 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     __syncthreads();
     if (!has_rows) return;
 
-    // masks of the row above the strip / below the strip (original state)
+    // masks of the row above the strip / below the strip (original state): neighbour strip through LDS,
+    // neighbour workgroup from the saved outer halos
     u64 Sp[4] = { 0, 0, 0, 0 }, Sb[4] = { 0, 0, 0, 0 };
     if (r0 > 0) {
-        if (wv > 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u64 v = halo[wv - 1][1][j];
-                Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
-            }
-        } else if (inplace) {   // workgroup's outer halo: masks of the ORIGINAL row, saved by wf_big_halo
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u64 v = outer[(size_t)blockIdx.x * 8 + j];
-                Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
-            }
-        } else {   // workgroup's outer halo: from global memory
-            uint4 up = inert;
-            if (active) up = src[(r0 - 1u) * LW];
-            still_masks(up, Sp);
+        for (int j = 0; j < 4; ++j) {
+            const u64 v = wv > 0 ? halo[wv - 1][1][j] : outer[(size_t)blockIdx.x * 8 + j];
+            Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
         }
     }
     if (r1 < H) {
-        if (wv < 3) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u64 v = halo[wv + 1][0][j];
-                Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
-            }
-        } else if (inplace) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u64 v = outer[(size_t)blockIdx.x * 8 + 4 + j];
-                Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
-            }
-        } else {
-            uint4 dn = inert;
-            if (active) dn = src[r1 * LW];
-            still_masks(dn, Sb);
+        for (int j = 0; j < 4; ++j) {
+            const u64 v = wv < 3 ? halo[wv + 1][0][j] : outer[(size_t)blockIdx.x * 8 + 4 + j];
+            Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
         }
     }
 
     // ---- sweep
-    uint32_t anyfire = 0, bhit = 0, healthy = 0;
-    u64 ign_x0 = 0, ign_xl = 0;
-    uint4 cur = first, nxt = inert;
-    u64 Sc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Sc[j] = Sf[j];
-    if (r0 + 1 < r1 && active) nxt = src[(r0 + 1u) * LW];
-    for (uint32_t r = r0; r < r1; ++r) {
-        uint4 nn = inert;                                        // prefetch row r+2
-        if (r + 2 < r1 && active) nn = src[(r + 2u) * LW];
-        u64 Sn[4];
-        if (r + 1 < r1) still_masks(nxt, Sn);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Sn[j] = Sb[j];
-        }
-        uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
-        u64 FIRE[4], GR[4];
-        if (step) {
-            u64 anyign = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
-                // fuel -= 1 and fire -> burnt (+0xFFFFFF01) unless still burning (+0xFFFFFF00): the burn-out
-                // lanes arrive as the carry-in of one add
-                c[j] = addc(c[j], lanebit(F) ? 0xFFFFFF00u : 0u, F & ~Sc[j]);
-                const u64 G = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);   // idle lanes hold inert (dirt) cells
-                // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows; every
-                // neighbour set is counted by one add-with-carry-in
-                const u64 LF = j > 0 ? Sc[(j + 3) & 3] : (Sc[3] << 1);
-                const u64 RT = j < 3 ? Sc[(j + 1) & 3] : (Sc[0] >> 1);
-                const uint32_t cnt = addc0(addc0(addc0(lanebit(Sp[j]) ? 1u : 0u, Sn[j]), LF), RT);
-                const uint32_t room = ign - ((c[j] >> 16) & 0xffu);
-                const u64 IGN = G & __ballot(cnt >= room);                     // apply_heat_from_to :278-294
-                const uint32_t cn = addc(c[j], min(cnt, room) << 16, IGN);     // heat saturates; grass -> fire (+1)
-                c[j] = lanebit(G) ? cn : c[j];
-                anyign |= IGN;
-                if (j == 0) ign_x0 |= IGN;                                      // cells with x == 0 (lane 0)
-                if (j == 3) ign_xl |= IGN;                                      // cells with x == W-1 (lane LW-1)
-                FIRE[j] = Sc[j] | IGN;
-                GR[j] = G & ~IGN;
-            }
-            // set_fire_to :245-246: first / last row of the grid are border rows
-            if ((r == 0 || r == H - 1) && anyign) bhit = 1;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
-                GR[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
-            }
-        }
-        if (reach_test) {   // does a burning cell sit on a border-connected cell?
-            typedef u64 u64x4 __attribute__((ext_vector_type(4)));
-            typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
-            const u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
-            reach_hit |= ((FIRE[0] & rb.x) | (FIRE[1] & rb.y) | (FIRE[2] & rb.z) | (FIRE[3] & rb.w)) ? 1u : 0u;
-        }
-        if (reduce) {
-            anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
-            healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
-        }
-        if (active && (!inplace || ((c[0] ^ cur.x) | (c[1] ^ cur.y) | (c[2] ^ cur.z) | (c[3] ^ cur.w))))
-            dst[r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { Sp[j] = Sc[j]; Sc[j] = Sn[j]; }
-        cur = nxt;
-        nxt = nn;
+    TiledAcc A = { 0, 0, 0, 0, 0, 0 };
+    if (step) {
+        if (reach_test) tiled_sweep<true, true>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
+        else tiled_sweep<true, false>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
+    } else {
+        if (reach_test) tiled_sweep<false, true>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
+        else tiled_sweep<false, false>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
     }
-    bhit |= ((ign_x0 & 1ull) | (ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
-    if (reduce && lane == 0) {
-        const uint32_t A = anyfire | (bhit << 1) | (reach_hit << 2);
-        if (A) atomicOr(&acc[2 * e], A);
-        if (healthy) atomicAdd(&acc[2 * e + 1], healthy);
+    A.bhit |= ((A.ign_x0 & 1ull) | (A.ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
+    if (lane == 0) {
+        const uint32_t R = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
+        if (R) atomicOr(&acc[2 * e], R);
+        if (A.healthy) atomicAdd(&acc[2 * e + 1], A.healthy);
     }
 }
 
