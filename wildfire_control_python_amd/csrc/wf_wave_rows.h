@@ -1,0 +1,494 @@
+// wf_wave_rows.h - single-step kernel, rows layout (several environments per wave iteration)
+// Included by wf_kernels.hip inside its anonymous namespace (one translation unit: the launchers there
+// instantiate these templates); not a stand-alone header.
+
+// ----------------------------------------------------------------------------
+// single-step kernel (n_steps == 1): ROWS layout, several environments per wave iteration
+// ----------------------------------------------------------------------------
+// A lane owns 1/S of a grid ROW (CPL = W/S consecutive cells = 4*CPL contiguous bytes), an
+// environment owns LPE = H*S consecutive lanes, and EPW environments sit side by side in the
+// wave, separated by S idle lanes, so that a ballot mask shifted by one grid row (S lanes) can
+// never leak into the neighbouring environment.  Compared with the 4-cells-per-lane layout of
+// wf_step_group (14x14: one environment on 49 lanes, 4 cell slots):
+//   * one pass over the CPL cell slots serves EPW environments (14x14, S=2: 7 slots for 2
+//     environments = 3.5 per environment), and so does every scalar mask operation;
+//   * left/right neighbours are mostly the lane's own neighbouring slots (a 0/1 register, no
+//     mask shift, no select); only the row seam inside a split row (S>1) needs a lane shift;
+//   * the EPW environments of an iteration are contiguous in memory (env stride = LPE lanes x
+//     4*CPL bytes), so the wave still moves one dense span per iteration.
+// Everything per-environment is expressed on lane masks (RUNM = lanes of running environments,
+// ...), never on divergent control flow; per-environment scalars are cut out of the masks with
+// the constant lane sets hm(h).  Phases A and C are those of wf_step_group; the environment
+// registers travel through LDS in both the private and the workgroup-shared variant.
+// environments per wave iteration: as many as fit with S idle lanes between them AND one idle lane above the
+// last one (the carry-out trick of the result extraction needs that lane: top lane index <= 62)
+constexpr int rg_epw(int H, int S) { return (63 + S) / (H * S + S); }
+
+constexpr u64 rg_lanes(int W, int H, int S, int kind, int j)
+{
+    const int LPE = H * S, PITCH = LPE + S, CPL = W / S, EPW = rg_epw(H, S);
+    u64 m = 0;
+    for (int h = 0; h < EPW; ++h)
+        for (int l = 0; l < LPE; ++l) {
+            const int y = l / S, x = (l % S) * CPL + j;
+            const bool b = kind == 0 ? true
+                         : kind == 1 ? (l % S != 0)
+                         : kind == 2 ? (l % S != S - 1)
+                         : kind == 3 ? (x == 0 || y == 0 || x == W - 1 || y == H - 1)
+                         : kind == 4 ? (y == 0 || y == H - 1)
+                                     : (l == LPE - 1);
+            if (b) m |= 1ull << (h * PITCH + l);
+        }
+    return m;
+}
+
+template <int W, int H, int S>
+struct RG {
+    static_assert(W % S == 0, "a row must split evenly over S lanes");
+    static constexpr int CELLS = W * H, CPL = W / S, LPE = H * S, PITCH = LPE + S;
+    static constexpr int EPW = rg_epw(H, S);
+    static_assert(LPE < 64 && EPW >= 1 && EPW * PITCH - S < 64, "environment does not fit the wave in this layout");
+    static constexpr u64 ENV0 = (1ull << LPE) - 1ull;
+    static constexpr u64 hm(int h) { return ENV0 << (h * PITCH); }          // lanes of environment h
+    static constexpr u64 CELL_LANES = rg_lanes(W, H, S, 0, 0);
+    static constexpr u64 NOT_ROWSTART = rg_lanes(W, H, S, 1, 0);
+    static constexpr u64 NOT_ROWEND = rg_lanes(W, H, S, 2, 0);
+    template <int J> static constexpr u64 BORDER = rg_lanes(W, H, S, 3, J);
+    static constexpr u64 ROW_EDGE = rg_lanes(W, H, S, 4, 0);                // lanes of the first and last grid row
+    static constexpr u64 COL_FIRST = CELL_LANES & ~NOT_ROWSTART;            // lanes whose slot 0 is column 0
+    static constexpr u64 COL_LAST = CELL_LANES & ~NOT_ROWEND;               // lanes whose last slot is column W-1
+    static constexpr u64 WRITERS = rg_lanes(W, H, S, 5, 0);                 // last lane of every environment
+    static constexpr int REACH_WORDS = CPL;                                   // u64 per group of EPW environments
+};
+
+template <int W, int H, int S>
+using RowMasks = u64[RG<W, H, S>::CPL];          // one lane mask per cell slot
+
+// neighbour sets of a per-slot cell set M (bit L of M[j] <-> slot j of lane L)
+template <int W, int H, int S, int J>
+__device__ __forceinline__ u64 rg_lf(const RowMasks<W, H, S> &M)
+{
+    using R = RG<W, H, S>;
+    if constexpr (J > 0) return M[J - 1];
+    else if constexpr (S > 1) return (M[R::CPL - 1] << 1) & R::NOT_ROWSTART;
+    else return 0ull;
+}
+template <int W, int H, int S, int J>
+__device__ __forceinline__ u64 rg_rt(const RowMasks<W, H, S> &M)
+{
+    using R = RG<W, H, S>;
+    if constexpr (J < R::CPL - 1) return M[J + 1];
+    else if constexpr (S > 1) return (M[0] >> 1) & R::NOT_ROWEND;
+    else return 0ull;
+}
+
+// cells of P reachable from the seed set R (in-place relaxation, wave-uniform loop)
+template <int W, int H, int S>
+__device__ __forceinline__ void flood_rows(RowMasks<W, H, S> &R, const RowMasks<W, H, S> &P)
+{
+    constexpr int CPL = RG<W, H, S>::CPL;
+    for (int it = 0; it < W * H; ++it) {
+        u64 any = 0;
+        static_for<CPL>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const u64 add = ((R[j] << S) | (R[j] >> S) | rg_lf<W, H, S, j>(R) | rg_rt<W, H, S, j>(R)) & P[j] & ~R[j];
+            R[j] |= add;
+            any |= add;
+        });
+        if (!any) break;
+    }
+}
+
+// N consecutive dwords at a 4-byte aligned address
+template <int N>
+__device__ __forceinline__ void load_dwords(const char *p, uint32_t *r)
+{
+    struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+    struct __attribute__((packed, aligned(4))) U3 { uint32_t x, y, z; };
+    struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; };
+    if constexpr (N >= 4) {
+        const U4 v = *reinterpret_cast<const U4 *>(p);
+        r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        if constexpr (N > 4) load_dwords<N - 4>(p + 16, r + 4);
+    } else if constexpr (N == 3) {
+        const U3 v = *reinterpret_cast<const U3 *>(p);
+        r[0] = v.x; r[1] = v.y; r[2] = v.z;
+    } else if constexpr (N == 2) {
+        const U2 v = *reinterpret_cast<const U2 *>(p);
+        r[0] = v.x; r[1] = v.y;
+    } else if constexpr (N == 1) {
+        r[0] = *reinterpret_cast<const uint32_t *>(p);
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_dwords(char *p, const uint32_t *r)
+{
+    struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+    struct __attribute__((packed, aligned(4))) U3 { uint32_t x, y, z; };
+    struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; };
+    if constexpr (N >= 4) {
+        *reinterpret_cast<U4 *>(p) = U4{ r[0], r[1], r[2], r[3] };
+        if constexpr (N > 4) store_dwords<N - 4>(p + 16, r + 4);
+    } else if constexpr (N == 3) {
+        *reinterpret_cast<U3 *>(p) = U3{ r[0], r[1], r[2] };
+    } else if constexpr (N == 2) {
+        *reinterpret_cast<U2 *>(p) = U2{ r[0], r[1] };
+    } else if constexpr (N == 1) {
+        *reinterpret_cast<uint32_t *>(p) = r[0];
+    }
+}
+
+// World.reset() of ONE environment of the iteration into the rows layout (same stream and
+// same law as reset_regs).  Every lane computes the cells "as if" it belonged to that
+// environment (y, xs = its row and first column); the lanes of HM (`mine`) keep them.
+// Returns the spawn cell in (s.ax, s.ay); writes the 4-cells-per-lane closed-form board too.
+template <int W, int H, int S>
+__device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint32_t e_ctx, uint32_t y, uint32_t xs,
+                                           uint32_t bgeo, u64 HM, bool mine, uint32_t (&c)[RG<W, H, S>::CPL], EnvS &s,
+                                           u64 *reach_e, bool writer)
+{
+    constexpr int CELLS = W * H, CPL = RG<W, H, S>::CPL;
+    cold_ptr cold = (cold_ptr)(uintptr_t)cold_g;
+    const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
+    const uint32_t ppm = cold->p.ignite_ppm;
+    const EnvKey key(seed, cold->p.env_id0 + (u64)e_ctx, s.episode);
+    const uint32_t r = below(key.draw(0), 3u);                        // radius - 1
+    const uint32_t k = below(key.draw(1), (uint32_t)cold->spawn.n[r]);   // point on the circle
+    const uint32_t fx = W / 2, fy = H / 2;                            // utility.py:61-64
+    const uint32_t sx = fx + (int)cold_g->spawn.dx[r][k], sy = fy + (int)cold_g->spawn.dy[r][k];
+    const uint32_t qc = fy * W + fx, qs = sy * W + sx;
+    const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1);
+    const uint32_t q0 = y * W + xs;
+    u64 onborder = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const uint32_t q = q0 + (uint32_t)j;
+        int32_t fuel = fuel_lo;
+        if (span > 1u) fuel += (int32_t)below(key.draw(16u + q), span);
+        uint32_t ty = WF_GRASS, heat = 0;
+        if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }         // set_fire_to :233-246
+        if (q == qs) ty = WF_DIRT;                                    // Agent.__init__ digs :111-113
+        bool extra = false;
+        if (ppm) extra = ty == WF_GRASS && below(key.draw(16u + CELLS + q), 1000000u) < ppm;
+        if (extra) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }
+        onborder |= __ballot(extra && ((bgeo >> j) & 1u));
+        const uint32_t fresh = ty | (((uint32_t)fuel & 0xffu) << 8) | (heat << 16) | (q == qs ? (1u << 24) : 0u);
+        c[j] = mine ? fresh : c[j];
+    }
+    onborder &= HM;
+    if (writer) {   // the closed-form board of the 4-cells-per-lane kernels (see reset_regs)
+        u64 rb[4];
+        static_for<4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            rb[j] = CM<W, H, j>::VALID & ~(((qs & 3u) == (uint32_t)j) ? (1ull << (qs >> 2)) : 0ull);
+        });
+        ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(reach_e);
+        rp[0] = make_ulonglong2(rb[0], rb[1]);
+        rp[1] = make_ulonglong2(rb[2], rb[3]);
+    }
+    s.ax = sx;
+    s.ay = sy;
+    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | WF_F_REACH_VALID | WF_F_REACH_ROWS |
+           (onborder ? WF_F_BORDER : 0u);
+    s.episode += 1;
+    s.tick = 0;
+}
+
+template <int W, int H, int S, bool SHARED>
+__global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(const WfArgs a)
+{
+    using R = RG<W, H, S>;
+    constexpr int CELLS = W * H, CPL = R::CPL, LPE = R::LPE, PITCH = R::PITCH, EPW = R::EPW;
+    constexpr uint32_t ENV_BYTES = CELLS * 4, OBS_BYTES = CELLS * 3;
+    const uint32_t lane = __lane_id();
+    const uint32_t batch = (uint32_t)a.batch;
+    const uint32_t G = (uint32_t)a.group;                   // environments per wave: multiple of EPW, <= 16
+    const uint32_t wv = rfl(threadIdx.x >> 6);
+    // B: this wave steps [e0, e0+ng);  A/C: lanes cover [A0, A0+na);  gi0: the wave's slice of the LDS arrays
+    uint32_t e0, ng, A0, na, gi0;
+    if constexpr (SHARED) {
+        const uint32_t per_wg = G * (blockDim.x >> 6);      // <= 64
+        A0 = blockIdx.x * per_wg;
+        na = min(per_wg, batch - A0);
+        gi0 = wv * G;
+        e0 = A0 + gi0;
+        ng = gi0 < na ? min(G, na - gi0) : 0u;
+    } else {
+        e0 = rfl(blockIdx.x * 4u + wv) * G;
+        if (e0 >= batch) return;
+        ng = min(G, batch - e0);
+        A0 = e0;
+        na = ng;
+        gi0 = wv * 16u;
+    }
+    const uint32_t ign = (uint32_t)a.ignite_count;
+    const bool do_update = (a.update_mask & 1ull) != 0;
+    char *planes_b = reinterpret_cast<char *>(a.planes);
+    __shared__ uint32_t sS[7][64];                           // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
+    enum { S_POS = 0, S_FL = 1, S_EP = 2, S_TICK = 3, S_P = 4, S_R = 5, S_CNT = 6 };
+
+    // ================= phase A: lanes = environments =================
+    const bool lane_env = lane < na;
+    const uint32_t ek = A0 + (lane_env ? lane : 0u);
+    const uint32_t ai = SHARED ? lane : gi0 + (lane_env ? lane : 0u);   // LDS slot of this env-lane
+    if (!SHARED || wv == 0) {
+        const EnvRegs S0 = group_phase_a<W, H, 8>(a, lane_env, ek, do_update);
+        if (lane_env) {
+            sS[S_POS][ai] = S0.ax | (S0.ay << 16);
+            sS[S_FL][ai] = S0.fl;
+            sS[S_EP][ai] = S0.episode;
+            sS[S_TICK][ai] = S0.tick;
+            sS[S_P][ai] = S0.Pv;
+            sS[S_R][ai] = 0;
+        }
+        if (SHARED && lane == 0) sS[S_CNT][0] = 0;
+        // Other waves of the workgroup read the touched bytes back: the stores must have landed.  The wave's
+        // own later loads need no wait: a wave's vector memory instructions reach its L1 in program order
+        // (wavefront-scope fences are no-ops in the AMDGPU memory model), the fence below only stops the compiler.
+        if (SHARED || WF_STORE_WAIT) __builtin_amdgcn_s_waitcnt(0);
+    }
+    if constexpr (SHARED) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ================= phase B: EPW environments at a time, lanes = row pieces =================
+    const uint32_t hh = lane / (uint32_t)PITCH, l = lane - hh * (uint32_t)PITCH;
+    const bool cell_lane = hh < (uint32_t)EPW && l < (uint32_t)LPE;
+    const uint32_t y = l / (uint32_t)S, xs = (l - y * (uint32_t)S) * (uint32_t)CPL;
+    // bit j: slot j of this lane is a border cell (needed by the rare reset path only)
+    uint32_t bgeo = (y == 0u || y == (uint32_t)(H - 1)) ? (1u << CPL) - 1u
+                  : ((xs == 0u ? 1u : 0u) | (xs + (uint32_t)CPL == (uint32_t)W ? 1u << (CPL - 1) : 0u));
+    uint32_t ob = hh * OBS_BYTES + (xs * H + y) * 3u;         // obs[x][y][k] image of the iteration's environments
+    asm volatile("" : "+v"(bgeo), "+v"(ob));
+    const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
+    constexpr int OBS_PAD = (EPW * OBS_BYTES + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) uint8_t sObs[SHARED ? 8 : 4][OBS_PAD];
+    uint8_t *obs_lds = sObs[wv];
+    typedef const u64 __attribute__((address_space(4))) *const_u64_ptr;
+    const bool cont = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
+
+    if (cell_lane && ng) {
+        // byte offset of this lane's cells in the current iteration; lanes whose environment does not
+        // exist (ragged tail) shadow environment 0 of the iteration for loads and sit out otherwise
+        uint32_t off = e0 * ENV_BYTES + l * (uint32_t)(CPL * 4);
+        uint32_t nxt[CPL];
+        load_dwords<CPL>(planes_b + (off + (hh < ng ? hh * ENV_BYTES : 0u)), nxt);
+        for (uint32_t kb = 0; kb < ng; kb += (uint32_t)EPW, off += (uint32_t)EPW * ENV_BYTES) {
+            if (kb + hh < ng) {
+                const uint32_t eoff = off + hh * ENV_BYTES;
+                uint32_t c[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) c[j] = nxt[j];
+#if WF_SKIP_CLEAN
+                uint32_t orig[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) orig[j] = nxt[j];
+#endif
+                load_dwords<CPL>(planes_b + (eoff + (kb + (uint32_t)EPW + hh < ng ? (uint32_t)EPW * ENV_BYTES : 0u)), nxt);
+                const uint32_t idx = gi0 + kb + hh;          // LDS slot of this lane's environment
+                const uint32_t Pl = sS[S_P][idx];
+                const u64 VM = __ballot(true);
+                const u64 RUNM = __ballot((Pl & PB_RUNNING) != 0u);
+                // border-reachability board of this group of EPW environments (context-level group index)
+                u64 *board = a.reach_rows + (size_t)((a.env_base + e0 + kb) / (uint32_t)EPW) * CPL;
+                u64 RBG[CPL];
+                bool rb_dirty = false;
+                if (cont) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) RBG[j] = ((const_u64_ptr)(uintptr_t)board)[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) RBG[j] = 0;
+                }
+                u64 WASRESET = 0;
+                if (RUNM != VM && (a.hot_flags & WF_HOT_AUTO_RESET)) {
+                    // ---- rare: finished environments start a new episode instead of stepping
+                    WASRESET = VM & ~RUNM;
+                    static_for<EPW>([&](auto HH) {
+                        constexpr int h = decltype(HH)::value;
+                        if (WASRESET & R::hm(h)) {
+                            const uint32_t ei = kb + (uint32_t)h;
+                            EnvS s = { 0, 0, 0, rfl(sS[S_EP][gi0 + ei]), 0 };
+                            const WfCold *cold = a.cold;
+                            uint32_t e_pin = e0 + ei;
+                            uint32_t y_pin = y, xs_pin = xs, bgeo_pin = bgeo, hh_pin = hh;     // keep the rare path's per-lane
+                            asm volatile("" : "+s"(cold), "+s"(e_pin), "+v"(y_pin), "+v"(xs_pin), "+v"(bgeo_pin), "+v"(hh_pin));   // work inside this branch
+                            cold_ptr cc = (cold_ptr)(uintptr_t)cold;
+                            reset_rows<W, H, S>(cold, cc->p.seed, e_pin + a.env_base, y_pin, xs_pin, bgeo_pin, R::hm(h), hh_pin == (uint32_t)h, c, s,
+                                                a.reach + (size_t)e_pin * 4, lane == (uint32_t)(h * PITCH));
+                            // rows board in closed form: every cell of the environment but the spawn cell
+                            const uint32_t sax = rfl(s.ax), say = rfl(s.ay);      // (loaded through the vector path: keep the boards scalar)
+                            const uint32_t sl = (uint32_t)(h * PITCH) + say * (uint32_t)S + sax / (uint32_t)CPL, sj = sax % (uint32_t)CPL;
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j)
+                                RBG[j] = (RBG[j] & ~R::hm(h)) | (R::hm(h) & ~(sj == (uint32_t)j ? (1ull << sl) : 0ull));
+                            rb_dirty = true;
+                            if (lane == (uint32_t)(h * PITCH)) {
+                                const uint32_t i = gi0 + ei;
+                                sS[S_POS][i] = s.ax | (s.ay << 16);
+                                sS[S_FL][i] = s.fl;
+                                sS[S_EP][i] = s.episode;
+                                sS[S_TICK][i] = s.tick;
+                            }
+                        }
+                    });
+                }
+                u64 FIREALL = 0, HITS = 0, BH = 0;                  // fire after the tick / fire on reachable cells / ignition on the border
+                if (do_update) {
+                    // ---- ForestFire.update (forest_fire.py:85-106)
+                    u64 STILL[CPL];
+                    uint32_t sv[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        // reduce_fuel (environment.py:297-307); finished environments hold no "fire" here
+                        const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & RUNM;
+                        STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
+                        const bool st = lanebit(STILL[j]);
+                        sv[j] = st ? 1u : 0u;
+                        const uint32_t d = st ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
+                        c[j] += lanebit(F) ? d : 0u;
+                    }
+                    u64 IGNANY = 0, IGN0 = 0, IGNL = 0;
+                    static_for<CPL>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294): burning neighbours
+                        // above / below come from the row masks, left / right mostly from the lane's own slots
+                        const u64 GR = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
+                        uint32_t cnt;
+                        if constexpr (j > 0 && j < CPL - 1) cnt = addc(sv[j - 1], sv[j + 1], STILL[j] << S);
+                        else if constexpr (CPL == 1) cnt = addc0(addc0(addc0(0u, STILL[j] << S), rg_lf<W, H, S, j>(STILL)), rg_rt<W, H, S, j>(STILL));
+                        else if constexpr (j == 0) cnt = S > 1 ? addc0(addc0(sv[j + 1], STILL[j] << S), rg_lf<W, H, S, j>(STILL)) : addc0(sv[j + 1], STILL[j] << S);
+                        else cnt = S > 1 ? addc0(addc0(sv[j - 1], STILL[j] << S), rg_rt<W, H, S, j>(STILL)) : addc0(sv[j - 1], STILL[j] << S);
+                        cnt = addc0(cnt, STILL[j] >> S);
+                        const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
+                        const u64 IGN = GR & __ballot(cnt >= room);
+                        const uint32_t cn = addc(c[j], min(cnt, room) << 16, IGN);     // heat saturates; grass -> fire (+1)
+                        c[j] = lanebit(GR) ? cn : c[j];
+                        IGNANY |= IGN;
+                        if constexpr (j == 0) IGN0 = IGN;
+                        if constexpr (j == CPL - 1) IGNL = IGN;
+                        const u64 FJ = STILL[j] | IGN;
+                        FIREALL |= FJ;
+                        HITS |= FJ & RBG[j];
+                    });
+                    // set_fire_to :245-246: a newly ignited border cell
+                    BH = (IGNANY & R::ROW_EDGE) | (IGN0 & R::COL_FIRST) | (IGNL & R::COL_LAST);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const u64 FJ = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & RUNM;
+                        FIREALL |= FJ;
+                        HITS |= FJ & RBG[j];
+                    }
+                }
+                // ---- containment part of World.get_reward (environment.py:345-377)
+                const u64 NEEDM = __ballot((Pl & PB_PRECHECK) != 0u && ((Pl & PB_VALID) == 0u || (Pl & PB_RING) != 0u)) & RUNM;
+                if (NEEDM) {
+                    // rare: the board of some environment is unknown or a dig may have cut a region off
+                    u64 PASS[CPL], NB[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
+                    static_for<CPL>([&](auto J) { constexpr int j = decltype(J)::value; NB[j] = R::template BORDER<j> & PASS[j]; });
+                    flood_rows<W, H, S>(NB, PASS);
+                    HITS = 0;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        RBG[j] = (RBG[j] & ~NEEDM) | (NB[j] & NEEDM);
+                        HITS |= __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & RUNM & RBG[j];
+                    }
+                    rb_dirty = true;
+                }
+                if (rb_dirty && lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) board[j] = RBG[j];
+                }
+                // ---- per-environment results.  "Any lane of my environment" without a loop over the
+                // environments: adding the all-ones lane set to a mask carries out of every environment
+                // that holds a bit, into the idle lane above it; one lane down sits the environment's
+                // last lane, which assembles and publishes the result word.
+                const u64 ANYW = (FIREALL + R::CELL_LANES) >> 1;
+                const u64 BHW = (BH + R::CELL_LANES) >> 1;
+                const u64 HITW = (HITS + R::CELL_LANES) >> 1;
+                const uint32_t any_l = lanebit(ANYW) ? 1u : 0u, bh_l = lanebit(BHW) ? 1u : 0u, hit_l = lanebit(HITW) ? 1u : 0u;
+                const uint32_t run_l = Pl & 1u, pre_l = (Pl >> 1) & run_l;
+                uint32_t Rl = any_l | (bh_l << 1) | ((pre_l & any_l & (bh_l ^ 1u) & (hit_l ^ 1u)) << 2) | (lanebit(NEEDM) ? (uint32_t)RB_RECOMPUTED : 0u);
+                const u64 OUTM = __ballot(run_l != 0u && any_l == 0u) & R::WRITERS;     // running, no fire left
+                if (OUTM) {                                                          // :384-387 burnt out (rare)
+                    u64 GRM[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) GRM[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
+                    static_for<EPW>([&](auto HH) {
+                        constexpr int h = decltype(HH)::value;
+                        if (OUTM & R::hm(h)) {
+                            uint32_t healthy = 0;
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) healthy += (uint32_t)__popcll(GRM[j] & R::hm(h));
+                            Rl |= hh == (uint32_t)h ? healthy << RB_HEALTHY_SHIFT : 0u;
+                        }
+                    });
+                }
+                Rl = lanebit(WASRESET) ? (uint32_t)RB_WASRESET : Rl;
+                if (l == (uint32_t)(LPE - 1)) sS[S_R][idx] = Rl;
+#if WF_SKIP_CLEAN
+                {   // most cells do not change in a tick: a lane whose row piece is unchanged writes nothing
+                    uint32_t chg = 0;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) chg |= c[j] ^ orig[j];
+                    if (chg) store_dwords<CPL>(planes_b + eoff, c);
+                }
+#else
+                store_dwords<CPL>(planes_b + eoff, c);
+#endif
+                if (a.obs) {
+                    // World.get_state() of the iteration's environments: byte triples into the LDS image at
+                    // their transposed offsets, then the image leaves as 16-byte stores
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const uint32_t t = c[j] & 0xffu, o = ob + (uint32_t)(j * H * 3);
+                        obs_lds[o] = (uint8_t)(c[j] >> 24);                       // agent_pos
+                        obs_lds[o + 1u] = (uint8_t)((2u >> t) & 1u);              // type == fire
+                        obs_lds[o + 2u] = (uint8_t)((7u >> t) & 1u);              // not dirt / water
+                    }
+                    const uint32_t nenv = min((uint32_t)EPW, ng - kb);
+                    const uint32_t nbytes = nenv * OBS_BYTES;                     // multiple of 4
+                    int8_t *obs_g = a.obs + (size_t)(e0 + kb) * OBS_BYTES;
+                    const uint32_t rank = (uint32_t)__popcll(VM & ((1ull << lane) - 1ull));   // dense index among the working lanes
+                    const uint32_t nwork = (uint32_t)__popcll(VM);
+                    struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+                    for (uint32_t o = rank * 16u; o < nbytes; o += nwork * 16u) {
+                        if (o + 16u <= nbytes) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(obs_lds + o);
+                            *reinterpret_cast<U4 *>(obs_g + o) = U4{ v.x, v.y, v.z, v.w };
+                        } else {
+                            for (uint32_t q = o; q < nbytes; q += 4u)
+                                *reinterpret_cast<uint32_t *>(obs_g + q) = *reinterpret_cast<const uint32_t *>(obs_lds + q);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ================= phase C: lanes = environments =================
+    if constexpr (SHARED) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(&sS[S_CNT][0], 1u);
+        if (rfl(old) != (blockDim.x >> 6) - 1u) return;     // not the last wave of the workgroup
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    {
+        EnvRegs S1;
+        const uint32_t pos = sS[S_POS][ai];
+        S1.ax = pos & 0xffffu;
+        S1.ay = pos >> 16;
+        S1.fl = sS[S_FL][ai];
+        S1.episode = sS[S_EP][ai];
+        S1.tick = sS[S_TICK][ai];
+        S1.Pv = sS[S_P][ai];
+        const uint32_t Rv = sS[S_R][ai];
+        group_phase_c<W, H, 8>(a, S1, Rv, lane_env, ek, do_update);
+    }
+}
+
