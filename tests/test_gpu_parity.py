@@ -579,6 +579,38 @@ def test_full_size_properties_65536x14x14(wf):
 
 
 # ---------------------------------------------------------------- consumers of the path
+def test_full_size_every_environment_matches_oracle(wf):
+    """BASELINE config 3 exactly as bench.py runs it (65 536 x 14x14, two half-batch launches of the rows
+    kernel per step, auto-reset, containment): every environment against the oracle, rewards and done flags
+    each step, the whole state at the end."""
+    B, S, T = 65536, 14, 40
+    env = wf.BatchedForestFire(B, size=S, seed=5, auto_reset=True, containment=True, fuel_range=(3, 25), ignite_ppm=3000)
+    assert env.step_launches == 2 and env.step_kernel.startswith("wf_step_rows")
+    env.reset(seed=5)
+    op = O.default_params(containment=1, fuel_lo=3, fuel_hi=25, ignite_ppm=3000)
+    planes, envs = O.new_state(B, S, S)
+    O.reset(planes, envs, seed=5, params=op)
+    rng = np.random.default_rng(5)
+    resets = 0
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        _, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op)
+        if stopped.any():
+            O.reset(planes, envs, seed=5, mask=stopped, params=op)
+            ro[stopped], do[stopped] = 0.0, 0
+            resets += int(stopped.sum())
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+    gp, ge = env.download()
+    np.testing.assert_array_equal(gp, planes)
+    np.testing.assert_array_equal(_envs(ge), envs)
+    np.testing.assert_array_equal(env.get_state(), O.get_state(planes))
+    assert resets > B // 4
+    env.close()
+
+
 @pytest.mark.parametrize("algo", ["DQN", "SARSA", "DDQN", "DSARSA"])
 def test_batched_learner_runs_on_the_device_api(wf, algo):
     """The four value-based learners of the reference, batched, drive the env through
