@@ -5,10 +5,11 @@ Workload (BASELINE.json configs[2], the one `metric` is quoted on): 65 536 batch
 14x14 grids per GPU, random fuel U{10..40}, agent dig-actions (uniform N/S/E/W)
 injected every step, containment test on, finished environments auto-reset on
 the device so every environment does real work in every timed step.
-A "step" = ONE wf_step_device launch = one ForestFire.step() for every env
-(one CA tick per launch: the honest HBM-bound shape; the fused multi-tick rate is
-reported separately as `fused`).  State and actions are resident in HBM before the
-timed region starts.
+A "step" = ONE wf_step_device call = one ForestFire.step() for every env = one CA
+tick (the library issues it as two concurrent half-batch launches on its own two
+streams; `roofline.single_launch` is the same step as one launch, and the rate of
+16 steps per call is reported separately as `steps_per_call`).  State and actions
+are resident in HBM before the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
