@@ -223,6 +223,8 @@ KERNEL_VARIANTS = {
     "rows-g2": {"WF_GROUP": "2"},
     "rows-g6-ragged": {"WF_GROUP": "6"},
     "rows-g8": {"WF_GROUP": "8"},
+    "rows-g32": {"WF_GROUP": "32", "WF_ROWS": "1"},
+    "rows-g22-ragged": {"WF_GROUP": "22", "WF_ROWS": "1"},
     "rows-shared-g8": {"WF_GROUP": "8", "WF_SHARED": "1"},
     "rows-shared-g16": {"WF_GROUP": "16", "WF_SHARED": "1"},
 }
@@ -231,7 +233,7 @@ KERNEL_VARIANTS = {
 @pytest.mark.parametrize("S", [14, 10])
 @pytest.mark.parametrize("variant", list(KERNEL_VARIANTS))
 def test_single_step_kernel_variants_match_oracle(wf, monkeypatch, variant, S):
-    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED"):
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED", "WF_ROWS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_VARIANTS[variant].items():
         monkeypatch.setenv(k, v)
@@ -635,7 +637,7 @@ def test_upload_and_kernel_switch_invalidate_reach_boards(wf, monkeypatch, varia
     (a ring of dirt dropped around the fire) and switching between the kernels that keep different copies
     (single step <-> fused multi-step) must never leave a stale board behind: containment is paid exactly when
     the oracle's flood pays it."""
-    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED"):
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED", "WF_ROWS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_VARIANTS[variant].items():
         monkeypatch.setenv(k, v)

@@ -325,7 +325,9 @@ StepPlan plan_single(const WfArgs &a, int num_cus)
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
     if constexpr (HasRows<W, H>::value) {
         constexpr int EPW = RG<W, H, HasRows<W, H>::S>::EPW;
-        if (p.G % EPW == 0 && p.G <= 16 && a.env_base % EPW == 0 && !getenv("WF_NO_ROWS"))
+        // G = 32 (batches >= 262 144): the group layout's dense 16-byte lanes win once the state outgrows the
+        // memory-side cache (7.5e11 vs 7.3e11 cell-updates/s at 262 144 x 14x14); WF_ROWS=1 forces rows there
+        if (p.G % EPW == 0 && (p.G <= 16 || (p.G <= 32 && getenv("WF_ROWS"))) && a.env_base % EPW == 0 && !getenv("WF_NO_ROWS"))
             p.kind = shared ? STEP_ROWS_SHARED : STEP_ROWS;
     }
     return p;

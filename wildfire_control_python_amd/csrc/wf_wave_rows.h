@@ -202,7 +202,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
     constexpr uint32_t ENV_BYTES = CELLS * 4, OBS_BYTES = CELLS * 3;
     const uint32_t lane = __lane_id();
     const uint32_t batch = (uint32_t)a.batch;
-    const uint32_t G = (uint32_t)a.group;                   // environments per wave: multiple of EPW, <= 16
+    const uint32_t G = (uint32_t)a.group;                   // environments per wave: multiple of EPW, <= 32
     const uint32_t wv = rfl(threadIdx.x >> 6);
     // B: this wave steps [e0, e0+ng);  A/C: lanes cover [A0, A0+na);  gi0: the wave's slice of the LDS arrays
     uint32_t e0, ng, A0, na, gi0;
@@ -219,12 +219,12 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
         ng = min(G, batch - e0);
         A0 = e0;
         na = ng;
-        gi0 = wv * 16u;
+        gi0 = wv * 32u;                                      // private slice of the LDS arrays (G <= 32)
     }
     const uint32_t ign = (uint32_t)a.ignite_count;
     const bool do_update = (a.update_mask & 1ull) != 0;
     char *planes_b = reinterpret_cast<char *>(a.planes);
-    __shared__ uint32_t sS[7][64];                           // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
+    __shared__ uint32_t sS[7][SHARED ? 64 : 128];            // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
     enum { S_POS = 0, S_FL = 1, S_EP = 2, S_TICK = 3, S_P = 4, S_R = 5, S_CNT = 6 };
 
     // ================= phase A: lanes = environments =================
