@@ -264,7 +264,6 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
     __shared__ __attribute__((aligned(16))) uint8_t sObs[SHARED ? 8 : 4][OBS_PAD];
     uint8_t *obs_lds = sObs[wv];
     typedef const u64 __attribute__((address_space(4))) *const_u64_ptr;
-    const bool cont = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
 
     if (cell_lane && ng) {
         // byte offset of this lane's cells in the current iteration; lanes whose environment does not
@@ -272,7 +271,9 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
         uint32_t off = e0 * ENV_BYTES + l * (uint32_t)(CPL * 4);
         uint32_t nxt[CPL];
         load_dwords<CPL>(planes_b + (off + (hh < ng ? hh * ENV_BYTES : 0u)), nxt);
-        for (uint32_t kb = 0; kb < ng; kb += (uint32_t)EPW, off += (uint32_t)EPW * ENV_BYTES) {
+        // board of the iteration's group (context-level group index), advanced with the loop
+        u64 *board = a.reach_rows + (size_t)((a.env_base + e0) / (uint32_t)EPW) * CPL;
+        for (uint32_t kb = 0; kb < ng; kb += (uint32_t)EPW, off += (uint32_t)EPW * ENV_BYTES, board += CPL) {
             if (kb + hh < ng) {
                 const uint32_t eoff = off + hh * ENV_BYTES;
                 uint32_t c[CPL];
@@ -288,17 +289,12 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
                 const uint32_t Pl = sS[S_P][idx];
                 const u64 VM = __ballot(true);
                 const u64 RUNM = __ballot((Pl & PB_RUNNING) != 0u);
-                // border-reachability board of this group of EPW environments (context-level group index)
-                u64 *board = a.reach_rows + (size_t)((a.env_base + e0 + kb) / (uint32_t)EPW) * CPL;
+                // border-reachability board of this group of EPW environments.  Always loaded: with the containment
+                // test off no environment carries the precheck bit, so whatever the board holds is never looked at.
                 u64 RBG[CPL];
                 bool rb_dirty = false;
-                if (cont) {
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) RBG[j] = ((const_u64_ptr)(uintptr_t)board)[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) RBG[j] = 0;
-                }
+                for (int j = 0; j < CPL; ++j) RBG[j] = ((const_u64_ptr)(uintptr_t)board)[j];
                 u64 WASRESET = 0;
                 if (RUNM != VM && (a.hot_flags & WF_HOT_AUTO_RESET)) {
                     // ---- rare: finished environments start a new episode instead of stepping
