@@ -72,3 +72,16 @@ class Episodes:
             exp_o, _ = self.expected_at(t, "obs")
             np.testing.assert_array_equal(obs[live], exp_o, err_msg=tag + " obs")
         return live
+
+
+def build_native_example(tmp_path):
+    """gcc examples/native_step.c (plain C client of include/wildfire.h) against the in-tree library."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "native_step")
+    libdir = os.path.join(repo, "wildfire_control_python_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(repo, "include"),
+                           os.path.join(repo, "examples", "native_step.c"), "-o", exe,
+                           "-L" + libdir, "-lwildfire_hip", "-Wl,-rpath," + libdir])
+    return exe

@@ -757,3 +757,34 @@ def test_external_stream_and_timer(wf):
     assert (r != 0).sum() > 512                         # most agents are still alive and were stepped
     np.testing.assert_array_equal(obs.cpu().numpy(), env.get_state())
     env.close()
+
+
+def test_plain_c_client_matches_python_path(wf, tmp_path):
+    """The same run through examples/native_step.c (plain C against include/wildfire.h) and through the Python
+    mirror: identical final state (FNV-1a checksum of the planes) and reward sum."""
+    import subprocess
+    from tests.golden_util import build_native_example
+    exe = build_native_example(tmp_path)
+    B, T = 1000, 60
+    r = subprocess.run([exe, str(B), str(T)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    env = wf.BatchedForestFire(B, size=14, auto_reset=True, fuel_range=(10, 40))
+    env.reset(seed=1234)
+    lcg = np.uint32(12345)
+    reward_sum = 0.0
+    with np.errstate(over="ignore"):
+        for t in range(T):
+            a = np.empty(B, dtype=np.int8)
+            for i in range(B):
+                lcg = np.uint32(lcg * np.uint32(1664525) + np.uint32(1013904223))
+                a[i] = int(lcg) >> 30
+            _, rew, _, _ = env.step(a)
+            reward_sum += float(rew.sum())
+    planes, _ = env.download()
+    h = 1469598103934665603
+    for b in planes.astype(np.uint8).ravel().tolist():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert f"state checksum {h:016x}" in out, out
+    assert f"reward sum {reward_sum:.1f}" in out, out
+    env.close()

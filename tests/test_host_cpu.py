@@ -197,3 +197,16 @@ def test_oracle_is_clean_under_asan_ubsan(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0 and "oracle clean" in out.stdout, out.stderr[-2000:]
+
+
+def test_plain_c_client_builds_and_fails_loudly_without_device(tmp_path):
+    """examples/native_step.c uses the boundary from plain C (gcc, no HIP headers, no Python).  Without a GPU
+    the library must refuse with WF_ERR_NO_DEVICE - there is no CPU fallback behind the C-ABI either."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    from tests.golden_util import build_native_example
+    exe = build_native_example(tmp_path)
+    r = subprocess.run([exe, "8", "1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no usable HIP device" in r.stderr, (r.returncode, r.stderr)
