@@ -788,3 +788,36 @@ def test_plain_c_client_matches_python_path(wf, tmp_path):
     assert f"state checksum {h:016x}" in out, out
     assert f"reward sum {reward_sum:.1f}" in out, out
     env.close()
+
+
+def test_bench_contract_single_and_two_ranks(wf):
+    """bench.py as the driver runs it: one JSON line with the contract's keys; the N = 2 launch through
+    torch.distributed.run (two ranks sharing this box's one GPU -> gloo carries the barrier) shards the
+    global batch and reports the whole-job rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(repo, "bench.py"), "--steps", "30", "--warmup", "5", "--batch", "16384", "--no-cpu-baseline"]
+    r1 = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, timeout=300, cwd=repo)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    lines = [l for l in r1.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r1.stdout
+    d1 = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d1, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d1["roofline"], k
+    assert d1["n_gpus"] == 1 and d1["steps"] == 30 and d1["scaling"] == "weak" and d1["vs_baseline"] is None
+    assert abs(d1["roofline"]["frac"] - d1["roofline"]["achieved"] / d1["roofline"]["peak"]) < 1e-9
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29533"] + base[1:] + ["--gpus", "2"],
+                        capture_output=True, text=True, timeout=400, cwd=repo, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    lines = [l for l in r2.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r2.stdout
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 2 * 16384 and d2["value"] > 0
