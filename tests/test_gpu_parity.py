@@ -82,7 +82,7 @@ def test_step_matches_oracle_random_actions(wf, W, H):
 
 
 # big-grid families: row-strip tiles with LDS halo masks (W % 4 == 0, W <= 256) and the generic
-# thread-per-cell kernel (any other shape).  No containment test there yet -> oracle containment off.
+# thread-per-cell kernel (any other shape).
 BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70, 6), (256, 256, 3),
               (11, 11, 128), (13, 10, 128), (30, 23, 48), (260, 9, 8)]
 
@@ -93,7 +93,7 @@ def test_big_grid_step_matches_oracle(wf, W, H, B):
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
                                auto_reset=(W == 24))
     assert "tiled" in env.kernel_name or "cells" in env.kernel_name
-    assert env.containment == ("tiled" in env.kernel_name)     # generic shapes: no containment test yet
+    assert env.containment                                       # both big-grid families test containment
     env.reset(seed=123)
     op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=int(env.containment))
     planes, envs = O.new_state(B, H, W)
@@ -165,8 +165,15 @@ def test_big_grid_split_equals_single_launch_and_oracle(wf, monkeypatch):
 
 
 def test_big_grid_containment_is_refused_not_ignored(wf):
+    """Where the containment test is not built (generic family beyond the flood kernel's LDS board, tiled
+    family beyond 1024 rows) asking for it is an error, never a silent no-op."""
     with pytest.raises(Exception):
-        wf.BatchedForestFire(4, size=11, containment=True)      # generic thread-per-cell family
+        wf.BatchedForestFire(1, width=301, height=301, containment=True)     # generic family, 90 601 cells
+    with pytest.raises(Exception):
+        wf.BatchedForestFire(1, width=8, height=1100, containment=True)      # tiled family, H > 1024
+    env = wf.BatchedForestFire(1, width=301, height=301)                     # default: falls back to "off", loudly visible
+    assert env.containment is False
+    env.close()
 
 
 def _circle_actions(ge, W, H, rng):
@@ -187,7 +194,7 @@ def _circle_actions(ge, W, H, rng):
     return a
 
 
-@pytest.mark.parametrize("W,H", [(24, 24), (32, 20), (14, 14)])
+@pytest.mark.parametrize("W,H", [(24, 24), (32, 20), (14, 14), (13, 13), (30, 23), (11, 14)])
 def test_containment_rewards_with_circling_agents(wf, W, H):
     """Agents that dig a ring around the fire: the +1000 containment reward (get_reward's A* part,
     environment.py:345-377) must appear exactly when and where the oracle pays it - tiled family

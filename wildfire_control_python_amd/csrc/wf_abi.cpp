@@ -237,7 +237,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     // the wave kernels address the planes with 32-bit byte offsets
     if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;
     // the containment test (get_reward's A* part) is built for the wave and tiled families
-    if (fam == WF_FAM_CELLS && pp.containment) return WF_ERR_UNSUPPORTED;
+    if (fam == WF_FAM_CELLS && pp.containment && (long long)H * W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;   // byte board in LDS
     if (fam == WF_FAM_TILED && pp.containment && H > 1024) return WF_ERR_UNSUPPORTED;   // boards live in LDS (64 KiB)
     if (fam != WF_FAM_WAVE && (unsigned long long)H * W > 0xFFFFull * 0xFFFFull) return WF_ERR_UNSUPPORTED;
 
@@ -288,7 +288,9 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         }
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
         // wave family: (batch,4) boards of the 4-cells-per-lane kernels + as much again for the rows layout
-        const size_t reach_words = fam == WF_FAM_WAVE ? (size_t)batch * 8 + 64 : (size_t)batch * H * 4;
+        // tiled family: u64[batch][H][4] lane masks; generic family: one byte per cell
+        const size_t reach_words = fam == WF_FAM_WAVE ? (size_t)batch * 8 + 64
+                                 : fam == WF_FAM_TILED ? (size_t)batch * H * 4 : ((size_t)batch * H * W + 7) / 8;
         if ((e = hipMalloc((void **)&c->reach, reach_words * sizeof(u64))) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_mask, (size_t)batch)) != hipSuccess) break;
         if ((e = hipMalloc((void **)&c->d_cold, sizeof(WfCold))) != hipSuccess) break;
@@ -336,7 +338,7 @@ int wf_destroy(wf_ctx *c)
 int wf_set_params(wf_ctx *c, const wf_params *p)
 {
     if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
-    if (c->fam == WF_FAM_CELLS && p->containment) return WF_ERR_UNSUPPORTED;
+    if (c->fam == WF_FAM_CELLS && p->containment && (long long)c->H * c->W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
@@ -498,7 +500,8 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.planes += (size_t)lo * cells;
             a.planes_out += (size_t)lo * cells;
             a.envs += lo;
-            a.reach += (size_t)lo * c->H * 4;
+            a.reach = c->fam == WF_FAM_TILED ? a.reach + (size_t)lo * c->H * 4
+                                             : reinterpret_cast<u64 *>(reinterpret_cast<uint8_t *>(a.reach) + (size_t)lo * cells);
             a.actions = d_actions ? d_actions + off + lo : nullptr;
             a.reward = d_reward ? d_reward + off + lo : nullptr;
             a.done = d_done ? d_done + off + lo : nullptr;

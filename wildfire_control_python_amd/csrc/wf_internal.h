@@ -75,6 +75,7 @@ hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num
 // big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out
 // halo != nullptr (tiled family): the step runs IN PLACE (planes_out == planes); halo = u64[batch][gx][8] scratch
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s);
+#define WF_CELLS_FLOOD_MAX 60000   // generic family: cells of a grid whose reachability byte board fits the flood kernel's LDS
 int wf_tiled_groups(int H);      // workgroups of wf_step_tiled per environment
 // sel == nullptr: all envs; sel_value >= 0: envs with sel[e] == sel_value; sel_value < 0: envs with sel[e] != 0
 hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s);

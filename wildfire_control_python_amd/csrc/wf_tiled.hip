@@ -420,6 +420,47 @@ __global__ __launch_bounds__(256) void wf_big_flood(const WfArgs a, const uint8_
     if (threadIdx.x == 0) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
 }
 
+// ---------------------------------------------------------------------------- flood, generic family
+// Border-reachability board of one environment as one byte per cell (1 = 4-connected to a passable border cell
+// through passable cells), for grid shapes that only the thread-per-cell kernel serves.  One workgroup per flagged
+// environment, the byte board lives in LDS (H*W <= WF_CELLS_FLOOD_MAX), Jacobi-free in-place relaxation until a
+// sweep changes nothing.
+__global__ __launch_bounds__(256) void wf_cells_flood(const WfArgs a, const uint8_t *mode)
+{
+    extern __shared__ uint8_t board[];               // [cells] 0 impassable, 1 passable, 3 passable + reached
+    __shared__ uint32_t changed;
+    const uint32_t e = blockIdx.x;
+    if (!(mode[e] & MODE_FLOOD)) return;
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
+    const uint32_t *se = a.planes + (size_t)e * cells;
+    for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
+        const uint32_t x = q % W, y = q / W;
+        const bool pass = (se[q] & 0xffu) < (uint32_t)WF_DIRT;
+        const bool edge = x == 0 || y == 0 || x == W - 1 || y == H - 1;
+        board[q] = pass ? (edge ? 3 : 1) : 0;
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < cells; ++it) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        bool ch = false;
+        for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
+            if (board[q] != 1) continue;
+            const uint32_t x = q % W, y = q / W;
+            const bool nb = (x > 0 && board[q - 1] == 3) || (x + 1 < W && board[q + 1] == 3) ||
+                            (y > 0 && board[q - W] == 3) || (y + 1 < H && board[q + W] == 3);
+            if (nb) { board[q] = 3; ch = true; }
+        }
+        if (ch) changed = 1;
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    uint8_t *out = reinterpret_cast<uint8_t *>(a.reach) + (size_t)e * cells;
+    for (uint32_t q = threadIdx.x; q < cells; q += 256u) out[q] = board[q] >> 1;
+    if (threadIdx.x == 0) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
+}
+
 // ---------------------------------------------------------------------------- generic step
 // Any grid shape: one thread per cell, neighbours read from the source planes.
 __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8_t *mode, uint32_t *acc)
@@ -452,6 +493,9 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
         a.planes_out[(size_t)e * cells + q] = c;
         if (m == MODE_STEP) {
             const uint32_t t = c & 0xffu;
+            // containment (environment.py:345-377): a burning cell on a border-connected cell
+            if ((mode[e] & MODE_PRECHECK) && t == WF_FIRE && reinterpret_cast<const uint8_t *>(a.reach)[(size_t)e * cells + q])
+                atomicOr(&acc[2 * e], 4u);
             // wave-aggregated when the whole wave sits in one env (the common case)
             const uint32_t e0 = rfl(e);
             if (__ballot(e != e0) == 0) {
@@ -539,6 +583,10 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     if (fam == WF_FAM_TILED && (a.hot_flags & WF_HOT_CONTAINMENT)) {
         const size_t lds_bytes = (size_t)a.H * 4 * 8 * 2;
         hipLaunchKernelGGL(wf_big_flood, dim3((unsigned)a.batch), dim3(256), lds_bytes, s, a, (const uint8_t *)mode);
+    }
+    if (fam == WF_FAM_CELLS && (a.hot_flags & WF_HOT_CONTAINMENT)) {
+        const size_t lds_bytes = ((size_t)a.H * a.W + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(wf_cells_flood, dim3((unsigned)a.batch), dim3(256), lds_bytes, s, a, (const uint8_t *)mode);
     }
     if (fam == WF_FAM_TILED) {
         const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
