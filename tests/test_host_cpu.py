@@ -62,7 +62,8 @@ def test_bad_arguments_rejected_before_touching_a_device():
     h = ctypes.c_void_p()
     p = N.default_params()
     assert lib.wf_create(ctypes.byref(h), 0, 0, 14, 14, ctypes.byref(p)) == -1       # batch 0
-    assert lib.wf_create(ctypes.byref(h), 0, 4, 11, 11, ctypes.byref(p)) == -2       # unsupported shape
+    assert lib.wf_create(ctypes.byref(h), 0, 1, 301, 301, ctypes.byref(p)) == -2     # containment beyond the generic flood board
+    assert lib.wf_create(ctypes.byref(h), 0, 1, 1100, 8, ctypes.byref(p)) == -2      # ... and beyond the tiled one (H > 1024)
     p.ignite_count = 0
     assert lib.wf_create(ctypes.byref(h), 0, 4, 14, 14, ctypes.byref(p)) == -1
     assert lib.wf_step(None, None, 1, 1, None, None) == -1
