@@ -452,7 +452,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
                 c->main_touched = false;
             }
             const int per = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
-            if (a.group <= 0) a.group = wf_pick_group((int)cells, c->num_cus, c->batch);   // as for the whole batch
+            if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);   // as for the whole batch
             for (int i = 0; i < c->n_parts; ++i) {
                 const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
                 if (lo >= hi) break;
@@ -612,7 +612,7 @@ const char *wf_step_kernel_name(const wf_ctx *c)
     if (!c) return "none";
     WfArgs a = base_args(c);
     if (splits(c, 1)) {
-        if (a.group <= 0) a.group = wf_pick_group(c->H * c->W, c->num_cus, c->batch);
+        if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);
         a.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
     }
     return wf_single_step_kernel(c->fam, a, c->num_cus);

@@ -67,6 +67,10 @@ static inline int wf_pick_group(int cells, int num_cus, long long batch)
     return G;
 }
 
+// The same, knowing the grid shape: shapes served by the rows-layout kernel keep G <= 8 - more, shorter waves than
+// resident slots beat longer waves at every batch from 131 072 up (75 vs 69 % of roofline at 131 072 x 14x14,
+// 80 vs 75 % at 262 144; a wash once the state outgrows the memory-side cache).
+int wf_pick_group_for(int W, int H, int num_cus, long long batch);
 
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
 const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus);

@@ -318,15 +318,14 @@ template <int W, int H>
 StepPlan plan_single(const WfArgs &a, int num_cus)
 {
     StepPlan p;
-    p.G = wf_pick_group(W * H, num_cus, a.batch);
+    p.G = wf_pick_group_for(W, H, num_cus, a.batch);
     const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
     if (a.group > 0) p.G = a.group < gmax ? a.group : gmax;
     const bool shared = getenv("WF_SHARED") && (p.G == 8 || p.G == 16) && a.batch >= 4096;
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
     if constexpr (HasRows<W, H>::value) {
         constexpr int EPW = RG<W, H, HasRows<W, H>::S>::EPW;
-        // G = 32 (batches >= 262 144): the group layout's dense 16-byte lanes win once the state outgrows the
-        // memory-side cache (7.5e11 vs 7.3e11 cell-updates/s at 262 144 x 14x14); WF_ROWS=1 forces rows there
+        // (wf_pick_group_for keeps G <= 16 for these shapes; an override beyond that needs WF_ROWS=1 to stay on rows)
         if (p.G % EPW == 0 && (p.G <= 16 || (p.G <= 32 && getenv("WF_ROWS"))) && a.env_base % EPW == 0 && !getenv("WF_NO_ROWS"))
             p.kind = shared ? STEP_ROWS_SHARED : STEP_ROWS;
     }
@@ -386,6 +385,17 @@ WfFamily wf_pick_family(int H, int W)
 #undef X
     if (W >= 4 && W <= 256 && W % 4 == 0 && H >= 1) return WF_FAM_TILED;
     return WF_FAM_CELLS;
+}
+
+int wf_pick_group_for(int W, int H, int num_cus, long long batch)
+{
+    int G = wf_pick_group(W * H, num_cus, batch);
+    bool rows = false;
+#define X(w, h) if (W == w && H == h) rows = HasRows<w, h>::value;
+    WF_WAVE_SHAPES(X)
+#undef X
+    if (rows && !getenv("WF_NO_ROWS") && G > 8) G = 8;
+    return G;
 }
 
 const char *wf_family_name(WfFamily f, int, int)
