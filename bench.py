@@ -191,8 +191,9 @@ def main():
         single_ms = env.timer_stop() / n_s
         del os.environ["WF_NO_SPLIT"]
 
-    # extra: n steps per API call (step_many).  Small batches run them in ONE launch with the grid in
-    # registers between ticks; large batches as n single-step launches, which is the faster of the two there.
+    # extra: n steps per API call (step_many).  Small batches run them in ONE launch with the grid in registers
+    # between ticks; large batches of a rows-layout shape in one launch per stream whose waves step their
+    # environments n times (a kernel boundary less per step), other large batches as n single-step launches.
     fused = None
     if args.fused > 1 and not args.no_extras:
         F = args.fused
@@ -208,7 +209,7 @@ def main():
             env.step_device(d_act_f, F, d_rew_f, d_done_f, update_mask=(1 << F) - 1)
         f_ms = env.timer_stop()
         fused = {"steps_per_call": F, "calls": reps,
-                 "launches_per_call": (F * env.step_launches if env.step_launches > 1 else 1),
+                 "launches_per_call": int(env._lib.wf_call_launches(env._h, F)),
                  "cell_updates_per_s_per_gpu": cells * F * reps / (f_ms * 1e-3)}
 
     # extra: step + observation.  Fused (the step kernel writes World.get_state() itself) against

@@ -170,6 +170,7 @@ int wf_timer_stop(wf_ctx *ctx, float *elapsed_ms);   /* synchronises */
 const char *wf_kernel_name(const wf_ctx *ctx);
 const char *wf_step_kernel_name(const wf_ctx *ctx);
 int wf_step_launches(const wf_ctx *ctx);
+int wf_call_launches(const wf_ctx *ctx, int n_steps);   /* kernel launches behind one wf_step*(n_steps) call */
 
 #ifdef __cplusplus
 }

@@ -293,6 +293,59 @@ def test_fused_steps_equal_single_steps(wf):
     e2.close()
 
 
+def test_multi_step_call_in_one_launch_matches_single_steps_and_oracle(wf, monkeypatch):
+    """step_many on a large batch of a rows-layout shape is ONE launch per stream whose waves step their
+    environments n times.  Same results as n single-step calls (WF_NO_MULTI=1) and as the oracle, with
+    auto-resets, containment floods (boards rewritten and re-read inside the launch) and a_speed-style masks."""
+    import ctypes
+    from wildfire_control_python_amd import _native as N
+    B, S, n, calls = 8192 + 64, 14, 7, 6
+    kw = dict(size=S, seed=21, auto_reset=True, containment=True, fuel_range=(3, 10))
+    a_env, b_env = wf.BatchedForestFire(B, **kw), wf.BatchedForestFire(B, **kw)
+    a_env.reset(seed=21)
+    b_env.reset(seed=21)
+    op = O.default_params(containment=1, fuel_lo=3, fuel_hi=10)
+    planes, envs = O.new_state(B, S, S)
+    O.reset(planes, envs, seed=21, params=op)
+    rng = np.random.default_rng(4)
+    paid = resets = 0
+    for call in range(calls):
+        a = rng.integers(0, 6, size=(n, B)).astype(np.int8)
+        a[:, :B // 2] = 5 if call == 0 else a[:, :B // 2]
+        for k in range(n):
+            a[k, :B // 3] = _circle_actions(envs[:B // 3], S, S, rng) if k == 0 else a[k, :B // 3]
+        mask = (1 << n) - 1 if call % 2 == 0 else 0b1011011          # some steps without update() (a_speed > 1)
+        ra, da = np.empty((n, B)), np.empty((n, B), dtype=np.uint8)
+        rb, db = np.empty((n, B)), np.empty((n, B), dtype=np.uint8)
+        obs_a = np.empty((B, S, S, 3), dtype=np.int8)
+        obs_b = np.empty_like(obs_a)
+        monkeypatch.delenv("WF_NO_MULTI", raising=False)
+        assert a_env._lib.wf_step_obs(a_env._h, N.ptr(a), n, ctypes.c_uint64(mask), N.ptr(ra), N.ptr(da), N.ptr(obs_a)) == 0
+        monkeypatch.setenv("WF_NO_MULTI", "1")
+        assert b_env._lib.wf_step_obs(b_env._h, N.ptr(a), n, ctypes.c_uint64(mask), N.ptr(rb), N.ptr(db), N.ptr(obs_b)) == 0
+        np.testing.assert_array_equal(ra, rb, err_msg=f"reward call {call}")
+        np.testing.assert_array_equal(da, db, err_msg=f"done call {call}")
+        np.testing.assert_array_equal(obs_a, obs_b, err_msg=f"obs call {call}")
+        for k in range(n):
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, a[k], op, do_update=bool((mask >> k) & 1))
+            if stopped.any():
+                O.reset(planes, envs, seed=21, mask=stopped, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+                resets += int(stopped.sum())
+            np.testing.assert_array_equal(ra[k], ro, err_msg=f"reward vs oracle call {call} step {k}")
+            np.testing.assert_array_equal(da[k], do, err_msg=f"done vs oracle call {call} step {k}")
+            paid += int((ro == 1000.0).sum())
+        np.testing.assert_array_equal(obs_a, O.get_state(planes), err_msg=f"obs vs oracle call {call}")
+    monkeypatch.delenv("WF_NO_MULTI", raising=False)
+    gp, ge = a_env.download()
+    np.testing.assert_array_equal(gp, planes)
+    np.testing.assert_array_equal(_envs(ge), envs)
+    assert resets > B // 8 and paid > 0, (resets, paid)
+    a_env.close()
+    b_env.close()
+
+
 def test_fused_multi_step_observation(wf):
     """wf_step_obs with n_steps > 1: the observation is that of the final state."""
     import ctypes

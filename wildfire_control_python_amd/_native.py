@@ -73,6 +73,7 @@ SYMBOLS = [
     ("wf_kernel_name", ctypes.c_char_p, [_vp]),
     ("wf_step_kernel_name", ctypes.c_char_p, [_vp]),
     ("wf_step_launches", _i, [_vp]),
+    ("wf_call_launches", _i, [_vp, _i]),
 ]
 
 _lib = None

@@ -105,6 +105,7 @@ WfArgs base_args(const wf_ctx *c)
     a.envs = c->envs;
     a.reach = c->reach;
     a.reach_rows = c->fam == WF_FAM_WAVE ? c->reach + (size_t)c->batch * 4 : nullptr;
+    a.step_stride = c->batch;
     a.cold = c->d_cold;
     a.batch = c->batch;
     a.H = c->H;
@@ -425,10 +426,18 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->fam == WF_FAM_WAVE) {
-        // Large batches: n_steps single-step launches (each split over the streams) beat the fused
-        // multi-step kernel, which keeps one environment per wave (5.7e11 vs 4.2e11 cell-updates/s at
-        // 65 536 x 14x14); small batches are launch-bound and take the fused kernel.
-        const bool each = n_steps > 1 && splits(c, 1);
+        // Large batches: one launch per stream whose waves step their environments n_steps times (shapes with a
+        // rows-layout kernel), else n_steps single-step launches; both beat the fused one-environment-per-wave
+        // kernel there (4.2e11 cell-updates/s at 65 536 x 14x14), which serves small, launch-bound batches.
+        bool in_kernel = false;
+        if (n_steps > 1 && splits(c, 1)) {
+            WfArgs probe = base_args(c);
+            probe.n_steps = n_steps;
+            probe.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+            if (probe.group <= 0) probe.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);
+            in_kernel = wf_multi_step_in_rows(c->fam, probe, c->num_cus);
+        }
+        const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
         const int n_launch = each ? n_steps : 1;
         const size_t cells = (size_t)c->H * c->W;
         for (int st = 0; st < n_launch; ++st) {
@@ -440,7 +449,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.done = d_done ? d_done + soff : nullptr;
             a.n_steps = each ? 1 : n_steps;
             a.update_mask = each ? (update_mask >> st) & 1ull : update_mask;
-            const bool split = splits(c, a.n_steps);
+            const bool split = splits(c, in_kernel ? 1 : a.n_steps);
             if (!split) {
                 JOIN(c);
                 HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
@@ -618,6 +627,19 @@ const char *wf_step_kernel_name(const wf_ctx *c)
         a.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
     }
     return wf_single_step_kernel(c->fam, a, c->num_cus);
+}
+
+int wf_call_launches(const wf_ctx *c, int n_steps)
+{
+    if (!c || n_steps < 1) return 0;
+    if (c->fam != WF_FAM_WAVE) return n_steps * (splits_big(c) ? c->n_parts : 1);      // launch sequences
+    if (!splits(c, 1)) return n_steps == 1 ? 1 : 1;                                     // one (fused) launch
+    if (n_steps == 1) return c->n_parts;
+    WfArgs probe = base_args(c);
+    probe.n_steps = n_steps;
+    probe.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+    if (probe.group <= 0) probe.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);
+    return wf_multi_step_in_rows(c->fam, probe, c->num_cus) ? c->n_parts : c->n_parts * n_steps;
 }
 
 int wf_step_launches(const wf_ctx *c)

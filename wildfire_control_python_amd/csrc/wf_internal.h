@@ -47,6 +47,8 @@ struct WfArgs {
     int32_t hot_flags;       // WF_HOT_*
     int32_t group;           // single-step group kernel: environments per wave
     uint32_t env_base;       // index of this launch's env 0 inside the context (split launches)
+    int32_t step_stride;     // environments in the whole context = row length of the (n_steps, batch) action / reward / done arrays
+    int32_t pad1;
     double default_reward, death_penalty, contained_bonus;
 };
 
@@ -74,6 +76,7 @@ int wf_pick_group_for(int W, int H, int num_cus, long long batch);
 
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
 const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus);
+bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, int num_cus);   // n_steps > 1 served by ONE launch of the rows kernel
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 // big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out

@@ -332,6 +332,10 @@ StepPlan plan_single(const WfArgs &a, int num_cus)
     return p;
 }
 
+}  // namespace
+bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, int num_cus);
+namespace {
+
 template <int W, int H>
 hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
 {
@@ -341,7 +345,7 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
     if (blocks < 1) blocks = 1;
     if (reset)
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.n_steps > 1)
+    else if (a.n_steps > 1 && !wf_multi_step_in_rows(WF_FAM_WAVE, a, num_cus))
         hipLaunchKernelGGL((wf_step_wave<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
     else {
         const StepPlan p = plan_single<W, H>(a, num_cus);
@@ -351,13 +355,14 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
         const dim3 grid_private((waves + 3) / 4), grid_shared((a.batch + 63) / 64), block_shared(64 * (64 / p.G));
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
-            if (p.kind == STEP_ROWS) hipLaunchKernelGGL((wf_step_rows<W, H, S, false>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false>), grid_private, dim3(256), 0, s, g);
             if (p.kind == STEP_ROWS_SHARED) {
                 // WF_SHARED=N with N in {2,4,8}: N waves share the agent phases (N*G <= 64 environments per workgroup)
                 int nw = atoi(getenv("WF_SHARED"));
                 if (nw < 2 || nw * p.G > 64) nw = 64 / p.G;
                 const int per_wg = nw * p.G;
-                hipLaunchKernelGGL((wf_step_rows<W, H, S, true>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
+                hipLaunchKernelGGL((wf_step_rows<W, H, S, true, false>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
             }
         }
         if (p.kind == STEP_GROUP) hipLaunchKernelGGL((wf_step_group<W, H, false>), grid_private, dim3(256), 0, s, g);
@@ -406,6 +411,18 @@ const char *wf_family_name(WfFamily f, int, int)
     case WF_FAM_CELLS: return "wf_step_cells (generic thread-per-cell)";
     default: return "none";
     }
+}
+
+// Large batches of a shape with a rows-layout kernel: an n_steps call is ONE launch of that kernel, every wave
+// stepping its environments n_steps times (small batches: the fused one-environment-per-wave kernel).
+bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, int num_cus)
+{
+    if (fam != WF_FAM_WAVE || a.step_stride <= 0 || a.batch < 4096 || getenv("WF_NO_MULTI")) return false;
+    StepPlan p = { 0, -1 };
+#define X(w, h) if (a.W == w && a.H == h) p = plan_single<w, h>(a, num_cus);
+    WF_WAVE_SHAPES(X)
+#undef X
+    return p.kind == STEP_ROWS;
 }
 
 // symbol of the kernel that would serve a single step of `a` (introspection for bench / profiles)

@@ -194,15 +194,16 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
     s.tick = 0;
 }
 
-template <int W, int H, int S, bool SHARED>
-__global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(const WfArgs a)
+// MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
+template <int W, int H, int S, bool SHARED, bool MULTI>
+__global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(const WfArgs a0)
 {
     using R = RG<W, H, S>;
     constexpr int CELLS = W * H, CPL = R::CPL, LPE = R::LPE, PITCH = R::PITCH, EPW = R::EPW;
     constexpr uint32_t ENV_BYTES = CELLS * 4, OBS_BYTES = CELLS * 3;
     const uint32_t lane = __lane_id();
-    const uint32_t batch = (uint32_t)a.batch;
-    const uint32_t G = (uint32_t)a.group;                   // environments per wave: multiple of EPW, <= 32
+    const uint32_t batch = (uint32_t)a0.batch;
+    const uint32_t G = (uint32_t)a0.group;                   // environments per wave: multiple of EPW, <= 32
     const uint32_t wv = rfl(threadIdx.x >> 6);
     // B: this wave steps [e0, e0+ng);  A/C: lanes cover [A0, A0+na);  gi0: the wave's slice of the LDS arrays
     uint32_t e0, ng, A0, na, gi0;
@@ -220,6 +221,26 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
         A0 = e0;
         na = ng;
         gi0 = wv * 32u;                                      // private slice of the LDS arrays (G <= 32)
+    }
+    // n_steps > 1: the wave simply steps its environments again (each wave owns its environments, so nothing has
+    // to be synchronised across waves); this spares a kernel boundary - 2.8 us of dispatch - per step and launch.
+    static_assert(!(SHARED && MULTI), "the workgroup-shared variant steps once");
+    const uint32_t nst = MULTI ? (uint32_t)a0.n_steps : 1u;
+    for (uint32_t st = 0; st < nst; ++st) {
+    WfArgs a = a0;
+    {
+        const size_t so = (size_t)st * (size_t)a0.step_stride;          // row of the (n_steps, context batch) arrays
+        if (a.actions) a.actions += so;
+        if (a.reward) a.reward += so;
+        if (a.done) a.done += so;
+        a.update_mask = a0.update_mask >> st;
+        if (st + 1u < nst) a.obs = nullptr;                             // the observation of the final state only
+        if (st) {
+            // boards this wave rewrote with vector stores in the previous step are read through the scalar cache
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_dcache_inv();
+            __builtin_amdgcn_s_waitcnt(0);
+        }
     }
     const uint32_t ign = (uint32_t)a.ignite_count;
     const bool do_update = (a.update_mask & 1ull) != 0;
@@ -279,11 +300,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
                 uint32_t c[CPL];
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) c[j] = nxt[j];
-#if WF_SKIP_CLEAN
-                uint32_t orig[CPL];
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) orig[j] = nxt[j];
-#endif
+                uint32_t chg = 0;                                   // nonzero: this lane's row piece changes in this step
                 load_dwords<CPL>(planes_b + (eoff + (kb + (uint32_t)EPW + hh < ng ? (uint32_t)EPW * ENV_BYTES : 0u)), nxt);
                 const uint32_t idx = gi0 + kb + hh;          // LDS slot of this lane's environment
                 const uint32_t Pl = sS[S_P][idx];
@@ -311,6 +328,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
                             cold_ptr cc = (cold_ptr)(uintptr_t)cold;
                             reset_rows<W, H, S>(cold, cc->p.seed, e_pin + a.env_base, y_pin, xs_pin, bgeo_pin, R::hm(h), hh_pin == (uint32_t)h, c, s,
                                                 a.reach + (size_t)e_pin * 4, lane == (uint32_t)(h * PITCH));
+                            chg |= hh == (uint32_t)h ? 1u : 0u;
                             // rows board in closed form: every cell of the environment but the spawn cell
                             const uint32_t sax = rfl(s.ax), say = rfl(s.ay);      // (loaded through the vector path: keep the boards scalar)
                             const uint32_t sl = (uint32_t)(h * PITCH) + say * (uint32_t)S + sax / (uint32_t)CPL, sj = sax % (uint32_t)CPL;
@@ -341,7 +359,9 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
                         const bool st = lanebit(STILL[j]);
                         sv[j] = st ? 1u : 0u;
                         const uint32_t d = st ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
-                        c[j] += lanebit(F) ? d : 0u;
+                        const uint32_t dd = lanebit(F) ? d : 0u;
+                        c[j] += dd;
+                        chg |= dd;
                     }
                     u64 IGNANY = 0, IGN0 = 0, IGNL = 0;
                     static_for<CPL>([&](auto J) {
@@ -357,8 +377,9 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
                         cnt = addc0(cnt, STILL[j] >> S);
                         const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
                         const u64 IGN = GR & __ballot(cnt >= room);
-                        const uint32_t cn = addc(c[j], min(cnt, room) << 16, IGN);     // heat saturates; grass -> fire (+1)
-                        c[j] = lanebit(GR) ? cn : c[j];
+                        const uint32_t add = lanebit(GR) ? min(cnt, room) << 16 : 0u;  // heat saturates (room >= 1 on grass)
+                        c[j] = addc(c[j], add, IGN);                                   // grass -> fire: +1 through the carry-in
+                        chg |= add;                                                    // (an ignition always comes with heat)
                         IGNANY |= IGN;
                         if constexpr (j == 0) IGN0 = IGN;
                         if constexpr (j == CPL - 1) IGNL = IGN;
@@ -424,16 +445,8 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
                 }
                 Rl = lanebit(WASRESET) ? (uint32_t)RB_WASRESET : Rl;
                 if (l == (uint32_t)(LPE - 1)) sS[S_R][idx] = Rl;
-#if WF_SKIP_CLEAN
-                {   // most cells do not change in a tick: a lane whose row piece is unchanged writes nothing
-                    uint32_t chg = 0;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) chg |= c[j] ^ orig[j];
-                    if (chg) store_dwords<CPL>(planes_b + eoff, c);
-                }
-#else
-                store_dwords<CPL>(planes_b + eoff, c);
-#endif
+                // most cells do not change in a tick: a lane whose row piece is unchanged writes nothing
+                if (chg || !WF_SKIP_CLEAN) store_dwords<CPL>(planes_b + eoff, c);
                 if (a.obs) {
                     // World.get_state() of the iteration's environments: byte triples into the LDS image at
                     // their transposed offsets, then the image leaves as 16-byte stores
@@ -486,5 +499,5 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(c
         const uint32_t Rv = sS[S_R][ai];
         group_phase_c<W, H, 8>(a, S1, Rv, lane_env, ek, do_update);
     }
+    }   // steps
 }
-
