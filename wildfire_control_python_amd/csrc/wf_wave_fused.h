@@ -28,6 +28,9 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 // single-step kernel counts the connected components exactly and refines the border case
 // (see wf_step_group).
 
+#ifndef WF_LB_ROWS_MULTI
+#define WF_LB_ROWS_MULTI 6   // rows kernel with the step loop: a few more live values; 6 waves per SIMD without spills
+#endif
 #ifndef WF_LB_ROWS
 #define WF_LB_ROWS 8   // rows kernel: 56 VGPRs, 8 waves per SIMD (fewer resident waves measured slower)
 #endif

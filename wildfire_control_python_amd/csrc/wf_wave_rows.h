@@ -196,7 +196,7 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
 
 // MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
 template <int W, int H, int S, bool SHARED, bool MULTI>
-__global__ __launch_bounds__(SHARED ? 512 : 256, WF_LB_ROWS) void wf_step_rows(const WfArgs a0)
+__global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_LB_ROWS) void wf_step_rows(const WfArgs a0)
 {
     using R = RG<W, H, S>;
     constexpr int CELLS = W * H, CPL = R::CPL, LPE = R::LPE, PITCH = R::PITCH, EPW = R::EPW;
