@@ -1,5 +1,5 @@
 """Long randomized differential run of the HIP step against the CPU oracle (not part of pytest).
-usage (GPU box): [WF_GROUP=8] python tools/soak.py [steps] [batch] [size] [seed]
+usage (GPU box): [WF_GROUP=8] [STEPS_PER_CALL=k] python tools/soak.py [steps] [batch] [size] [seed]
 Every step: rewards and done flags; every 25 steps: full planes, records and the observation."""
 import os
 import sys
@@ -23,6 +23,8 @@ O.reset(planes, envs, seed=seed, params=op)
 rng = np.random.default_rng(seed)
 t0 = time.time()
 paid = resets = deaths = 0
+KPC = int(os.environ.get("STEPS_PER_CALL", "1"))
+pending = []                       # (actions, device reward, device done) of a multi-step call being replayed
 for t in range(T):
     a = rng.integers(0, 6, size=B).astype(np.int8)
     # a third of the agents walk in circles (rings -> floods, containment), the rest wander
@@ -31,7 +33,15 @@ for t in range(T):
     m = S // 2
     a[:k] = np.where((x >= m) & (y > m), rng.choice([1, 3], k), np.where((x > m) & (y <= m), rng.choice([1, 2], k),
                      np.where((x <= m) & (y < m), rng.choice([0, 2], k), rng.choice([0, 3], k))))
-    obs, r, d, _ = env.step(a)
+    if KPC > 1:
+        if not pending:            # draw the whole call's actions now (the circle policy then lags by < KPC steps)
+            acts = [a] + [rng.integers(0, 6, size=B).astype(np.int8) for _ in range(KPC - 1)]
+            rr, dd = env.step_many(np.stack(acts))
+            pending = [(acts[i], rr[i], dd[i].astype(bool)) for i in range(KPC)]
+        a, r, d = pending.pop(0)
+        obs = None
+    else:
+        obs, r, d, _ = env.step(a)
     stopped = (envs["flags"] & O.F_RUNNING) == 0
     ro, do = O.step(planes, envs, a, op)
     if stopped.any():
@@ -42,13 +52,13 @@ for t in range(T):
     assert np.array_equal(d, do.astype(bool)), f"done t={t}"
     paid += int((ro == 1000.0).sum())
     deaths += int((ro == -1000.0).sum())
-    if t % 25 == 0 or t == T - 1:
+    if (t % 25 == 0 or t == T - 1) and not pending:
         gp, ge = env.download()
         ge = ge.copy()
         ge["flags"] &= VIS
         assert np.array_equal(gp, planes), f"planes t={t}: envs {np.unique(np.nonzero(gp != planes)[0])[:8]}"
         assert np.array_equal(ge, envs), f"records t={t}"
-        assert np.array_equal(obs, O.get_state(planes)), f"obs t={t}"
+        assert np.array_equal(env.get_state() if obs is None else obs, O.get_state(planes)), f"obs t={t}"
     if t % 250 == 0:
         print(f"t={t} ok  resets={resets} contained={paid} deaths={deaths}  {time.time() - t0:.0f}s", flush=True)
 print(f"SOAK OK kernel={env.step_kernel} x{env.step_launches}: {T} steps x {B} envs {S}x{S}, resets={resets} contained={paid} deaths={deaths}")
