@@ -126,8 +126,12 @@ def test_big_grid_split_equals_single_launch_and_oracle(wf, monkeypatch):
     W = H = 64
     B, T = 2100, 24
     kw = dict(width=W, height=H, seed=9, auto_reset=True, containment=True, fuel_range=(2, 5), ignite_ppm=30000)
-    a_env, b_env = wf.BatchedForestFire(B, **kw), wf.BatchedForestFire(B, **kw)
-    assert a_env.step_launches == 2
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    a_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.setenv("WF_NO_SPLIT", "1")               # the WF_* switches are read when a context is created
+    b_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    assert a_env.step_launches == 2 and b_env.step_launches == 1
     a_env.reset(seed=9)
     b_env.reset(seed=9)
     op = O.default_params(containment=1, fuel_lo=2, fuel_hi=5, ignite_ppm=30000)
@@ -137,9 +141,7 @@ def test_big_grid_split_equals_single_launch_and_oracle(wf, monkeypatch):
     resets = 0
     for t in range(T):
         a = rng.integers(0, 5, size=B).astype(np.int8)
-        monkeypatch.delenv("WF_NO_SPLIT", raising=False)
         obs_a, r_a, d_a, _ = a_env.step(a)
-        monkeypatch.setenv("WF_NO_SPLIT", "1")
         obs_b, r_b, d_b, _ = b_env.step(a)
         stopped = (envs["flags"] & O.F_RUNNING) == 0
         ro, do = O.step(planes, envs, a, op)
@@ -152,7 +154,6 @@ def test_big_grid_split_equals_single_launch_and_oracle(wf, monkeypatch):
         np.testing.assert_array_equal(obs_a, obs_b, err_msg=f"obs t={t}")
         np.testing.assert_array_equal(r_a, ro, err_msg=f"reward vs oracle t={t}")
         np.testing.assert_array_equal(d_a, do.astype(bool), err_msg=f"done vs oracle t={t}")
-    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
     pa, ea = a_env.download()
     pb, eb = b_env.download()
     np.testing.assert_array_equal(pa, pb)
@@ -301,7 +302,12 @@ def test_multi_step_call_in_one_launch_matches_single_steps_and_oracle(wf, monke
     from wildfire_control_python_amd import _native as N
     B, S, n, calls = 8192 + 64, 14, 7, 6
     kw = dict(size=S, seed=21, auto_reset=True, containment=True, fuel_range=(3, 10))
-    a_env, b_env = wf.BatchedForestFire(B, **kw), wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_NO_MULTI", raising=False)
+    a_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.setenv("WF_NO_MULTI", "1")               # read at construction
+    b_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_NO_MULTI", raising=False)
+    assert a_env._lib.wf_call_launches(a_env._h, n) == 2 and b_env._lib.wf_call_launches(b_env._h, n) == 2 * n
     a_env.reset(seed=21)
     b_env.reset(seed=21)
     op = O.default_params(containment=1, fuel_lo=3, fuel_hi=10)
@@ -319,9 +325,7 @@ def test_multi_step_call_in_one_launch_matches_single_steps_and_oracle(wf, monke
         rb, db = np.empty((n, B)), np.empty((n, B), dtype=np.uint8)
         obs_a = np.empty((B, S, S, 3), dtype=np.int8)
         obs_b = np.empty_like(obs_a)
-        monkeypatch.delenv("WF_NO_MULTI", raising=False)
         assert a_env._lib.wf_step_obs(a_env._h, N.ptr(a), n, ctypes.c_uint64(mask), N.ptr(ra), N.ptr(da), N.ptr(obs_a)) == 0
-        monkeypatch.setenv("WF_NO_MULTI", "1")
         assert b_env._lib.wf_step_obs(b_env._h, N.ptr(a), n, ctypes.c_uint64(mask), N.ptr(rb), N.ptr(db), N.ptr(obs_b)) == 0
         np.testing.assert_array_equal(ra, rb, err_msg=f"reward call {call}")
         np.testing.assert_array_equal(da, db, err_msg=f"done call {call}")
@@ -337,7 +341,6 @@ def test_multi_step_call_in_one_launch_matches_single_steps_and_oracle(wf, monke
             np.testing.assert_array_equal(da[k], do, err_msg=f"done vs oracle call {call} step {k}")
             paid += int((ro == 1000.0).sum())
         np.testing.assert_array_equal(obs_a, O.get_state(planes), err_msg=f"obs vs oracle call {call}")
-    monkeypatch.delenv("WF_NO_MULTI", raising=False)
     gp, ge = a_env.download()
     np.testing.assert_array_equal(gp, planes)
     np.testing.assert_array_equal(_envs(ge), envs)
@@ -444,8 +447,12 @@ def test_split_launch_equals_single_launch_and_oracle(wf, monkeypatch):
     including auto-resets in the second half (the stream is keyed by the env's context index)."""
     B, S, T = 16384 + 192, 14, 70          # ragged: the halves are 8320 and 8256 environments
     kw = dict(size=S, seed=77, auto_reset=True, fuel_range=(3, 9))
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
     a_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.setenv("WF_NO_SPLIT", "1")               # read at construction
     b_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    assert a_env.step_launches == 2 and b_env.step_launches == 1
     a_env.reset(seed=77)
     b_env.reset(seed=77)
     op = O.default_params(fuel_lo=3, fuel_hi=9)
@@ -459,9 +466,7 @@ def test_split_launch_equals_single_launch_and_oracle(wf, monkeypatch):
     resets = 0
     for t in range(T):
         a = rng.integers(0, 5, size=B).astype(np.int8)
-        monkeypatch.delenv("WF_NO_SPLIT", raising=False)
         obs_a, r_a, d_a, _ = a_env.step(a)
-        monkeypatch.setenv("WF_NO_SPLIT", "1")
         obs_b, r_b, d_b, _ = b_env.step(a)
         np.testing.assert_array_equal(obs_a, obs_b, err_msg=f"obs t={t}")
         np.testing.assert_array_equal(r_a, r_b, err_msg=f"reward t={t}")
@@ -475,7 +480,6 @@ def test_split_launch_equals_single_launch_and_oracle(wf, monkeypatch):
                 ro[:], do[:] = 0.0, 0
                 resets += 1
             assert r_a[i] == ro[0] and bool(d_a[i]) == bool(do[0]), (t, i)
-    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
     pa, ea = a_env.download()
     pb, eb = b_env.download()
     np.testing.assert_array_equal(pa, pb)
@@ -590,7 +594,6 @@ def test_adapter_string_and_int_actions(wf):
     sim.step(np.int64(1))
     assert (sim.W.agents[0].x, sim.W.agents[0].y) == (x0, y0 + 1)
     assert sim.W.env.shape == (10, 10, 9) and sim.W.env[x0, y0, 0] == 3
-    assert not sim.W.agents[0].fire_in_direction(0) or True
     assert len(sim.W.border_points) == 40
     sim.close()
 
@@ -638,6 +641,177 @@ def test_full_size_properties_65536x14x14(wf):
     np.testing.assert_array_equal(prev, p2)
     for e in (big, big2, small):
         e.close()
+
+
+# ------------------------------------------------- BASELINE configs at their stated sizes
+def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
+    """BASELINE configs[1] exactly: 4 096 batched 10x10 grids, random fuel U{10..40}, no agent action, 16 ticks per
+    call (one fused launch, grids in registers between ticks): whole state, rewards and done flags vs the oracle."""
+    B, S, n = 4096, 10, 16
+    env = wf.BatchedForestFire(B, size=S, seed=1234, fuel_range=(10, 40))
+    assert env._lib.wf_call_launches(env._h, n) == 1
+    env.reset(seed=1234)
+    op = O.default_params(fuel_lo=10, fuel_hi=40)
+    planes, envs = O.new_state(B, S, S)
+    O.reset(planes, envs, seed=1234, params=op)
+    for call in range(14):                                       # 224 ticks: every episode ends
+        r, d = env.step_many(None, n)
+        for k in range(n):
+            ro, do = O.step(planes, envs, None, op)
+            np.testing.assert_array_equal(r[k], ro, err_msg=f"reward call {call} tick {k}")
+            np.testing.assert_array_equal(d[k], do.astype(bool), err_msg=f"done call {call} tick {k}")
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes call {call}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs call {call}")
+    assert d[-1].all()
+    np.testing.assert_array_equal(env.get_state(), O.get_state(planes))
+    env.close()
+
+
+def test_config4_1024x256x256_full_size(wf, monkeypatch):
+    """BASELINE configs[3] at its stated size: 1 024 batched 256x256 grids, ~1 % of the cells pre-ignited, fuel
+    U{10..40}.  The job takes the two-stream split of the in-place tiled kernel (wf_big_halo -> wf_step_tiled on two
+    shares of the batch); a WF_NO_SPLIT twin must agree bit for bit on every plane, a strided sample of 32
+    environments (both shares, the seam and the last env) is replayed by the oracle, and the monotonicity laws
+    of the rule are checked on ALL cells.  30 no-op ticks (the configuration), then 12 steps with agents digging."""
+    B, S = 1024, 256
+    kw = dict(size=S, seed=44, fuel_range=(10, 40), ignite_ppm=10000, containment=True)
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    a_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.setenv("WF_NO_SPLIT", "1")
+    b_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_NO_SPLIT", raising=False)
+    assert a_env.step_launches == 2 and b_env.step_launches == 1 and a_env.step_kernel == "wf_step_tiled"
+    a_env.reset(seed=44)
+    b_env.reset(seed=44)
+    idx = np.unique(np.concatenate([np.arange(0, B, 37), [510, 511, 512, 513, B - 1]]))
+    assert len(idx) >= 32
+    op = O.default_params(fuel_lo=10, fuel_hi=40, ignite_ppm=10000, containment=1)
+    p0, e0 = a_env.download()
+    assert 0.008 < (p0[..., 0] == 1).mean() < 0.012               # ~1 % of the cells burn from tick 0
+    sp, se = np.ascontiguousarray(p0[idx]), _envs(e0[idx]).astype(O.ENV_DTYPE)
+    # the sample's reset itself: oracle reset of those global ids
+    for k, i in enumerate(idx):
+        pl, en = O.new_state(1, S, S)
+        O.reset(pl, en, seed=44, env_id0=int(i), params=op)
+        np.testing.assert_array_equal(pl[0], sp[k], err_msg=f"reset env {i}")
+    rng = np.random.default_rng(44)
+    prev = p0
+    for t in range(42):
+        a = None if t < 30 else rng.integers(0, 5, size=B).astype(np.int8)
+        _, ra, da, _ = a_env.step(a)
+        _, rb, db, _ = b_env.step(a)
+        np.testing.assert_array_equal(ra, rb, err_msg=f"split vs single: reward t={t}")
+        np.testing.assert_array_equal(da, db, err_msg=f"split vs single: done t={t}")
+        ro, do = O.step(sp, se, None if a is None else a[idx], op)
+        np.testing.assert_array_equal(ra[idx], ro, err_msg=f"reward vs oracle t={t}")
+        np.testing.assert_array_equal(da[idx], do.astype(bool), err_msg=f"done vs oracle t={t}")
+        if t % 7 == 6 or t == 41:
+            p, e = a_env.download()
+            np.testing.assert_array_equal(p[idx], sp, err_msg=f"planes vs oracle t={t}")
+            np.testing.assert_array_equal(_envs(e[idx]), se, err_msg=f"envs vs oracle t={t}")
+            # fuel never increases, heat never decreases, burnt / dirt are absorbing, at most one agent cell
+            assert (p[..., 1] <= prev[..., 1]).all()
+            assert (p[..., 2] >= prev[..., 2]).all()
+            assert ((prev[..., 0] == 2) <= (p[..., 0] >= 2)).all()
+            assert ((prev[..., 0] == 3) <= (p[..., 0] == 3)).all()
+            assert (p[..., 3].reshape(B, -1).sum(axis=1) <= 1).all()
+            prev = p
+    pb, eb = b_env.download()
+    np.testing.assert_array_equal(prev, pb, err_msg="split vs single launch: planes")
+    np.testing.assert_array_equal(e, eb, err_msg="split vs single launch: records")
+    assert (prev[..., 0] == 1).mean() > 0.02                      # the fronts have spread
+    a_env.close()
+    b_env.close()
+
+
+def test_config5_last_shard_125000_envs_global_ids(wf):
+    """BASELINE configs[4], the LAST of the 8 shards: 125 000 environments holding global ids 875 000 .. 999 999
+    (ragged halves of 62 528 / 62 472 environments), bench inputs (fuel U{10..40}, uniform N/S/E/W, containment,
+    device auto-reset).  A strided sample is replayed by the oracle under the sample's global ids, and a
+    65 536-environment context holding ids 900 000 .. 965 535 must hold exactly the same state."""
+    B, S, T, ID0 = 125000, 14, 48, 875000
+    OFF, BS = 25000, 65536
+    kw = dict(size=S, seed=7, auto_reset=True, containment=True, fuel_range=(10, 40))
+    big = wf.BatchedForestFire(B, env_id0=ID0, **kw)
+    sub = wf.BatchedForestFire(BS, env_id0=ID0 + OFF, **kw)
+    assert big.step_launches == 2 and big.step_kernel.startswith("wf_step_rows")
+    big.reset(seed=7)
+    sub.reset(seed=7)
+    op = O.default_params(containment=1, fuel_lo=10, fuel_hi=40)
+    idx = np.unique(np.concatenate([np.arange(0, B, 1009), [62527, 62528, 62529, B - 2, B - 1]]))
+    p0, e0 = big.download()
+    samples = []
+    for i in idx:
+        pl, en = O.new_state(1, S, S)
+        O.reset(pl, en, seed=7, env_id0=ID0 + int(i), params=op)
+        np.testing.assert_array_equal(pl[0], p0[i], err_msg=f"reset env {i}")
+        samples.append((pl, en))
+    rng = np.random.default_rng(7)
+    resets = 0
+    for t in range(T):
+        a = rng.integers(0, 4, size=B).astype(np.int8)
+        _, r, d, _ = big.step(a)
+        _, rs, ds, _ = sub.step(a[OFF:OFF + BS])
+        np.testing.assert_array_equal(r[OFF:OFF + BS], rs, err_msg=f"shard vs sub-context: reward t={t}")
+        np.testing.assert_array_equal(d[OFF:OFF + BS], ds, err_msg=f"shard vs sub-context: done t={t}")
+        for k, i in enumerate(idx):
+            pl, en = samples[k]
+            stopped = (en["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(pl, en, a[i:i + 1], op)
+            if stopped.any():
+                O.reset(pl, en, seed=7, mask=stopped, env_id0=ID0 + int(i), params=op)
+                ro[:], do[:] = 0.0, 0
+                resets += 1
+            assert r[i] == ro[0] and bool(d[i]) == bool(do[0]), (t, i, r[i], ro[0])
+    p, e = big.download()
+    ps, es = sub.download()
+    np.testing.assert_array_equal(p[OFF:OFF + BS], ps)
+    np.testing.assert_array_equal(_envs(e[OFF:OFF + BS]), _envs(es))
+    for k, i in enumerate(idx):
+        np.testing.assert_array_equal(p[i], samples[k][0][0], err_msg=f"env {i}")
+        np.testing.assert_array_equal(_envs(e[i:i + 1]), samples[k][1], err_msg=f"record {i}")
+    assert resets > len(idx) // 2
+    big.close()
+    sub.close()
+
+
+@pytest.mark.parametrize("B,split", [(8193, None), (8255, None), (4 * 4096 + 130, "4")])
+def test_multi_step_split_with_a_ragged_last_part(wf, monkeypatch, B, split):
+    """A multi-step call of a split context whose LAST part is smaller than 4 096 environments (8 193 -> 4 160 +
+    4 033; WF_SPLIT=4 with 16 514 -> 3 x 4 160 + 4 034): every part must run the same kernel with the context's
+    row stride for actions / reward / done and the context-level environment index for the reset stream."""
+    monkeypatch.delenv("WF_SPLIT", raising=False)
+    if split:
+        monkeypatch.setenv("WF_SPLIT", split)
+    S, n = 14, 5
+    env = wf.BatchedForestFire(B, size=S, seed=13, auto_reset=True, containment=True, fuel_range=(3, 8))
+    monkeypatch.delenv("WF_SPLIT", raising=False)
+    parts = int(split or 2)
+    assert env.step_launches == parts and env._lib.wf_call_launches(env._h, n) == parts
+    env.reset(seed=13)
+    op = O.default_params(containment=1, fuel_lo=3, fuel_hi=8)
+    planes, envs = O.new_state(B, S, S)
+    O.reset(planes, envs, seed=13, params=op)
+    rng = np.random.default_rng(B)
+    resets = 0
+    for call in range(8):
+        a = rng.integers(0, 5, size=(n, B)).astype(np.int8)
+        r, d = env.step_many(a)
+        for k in range(n):
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, a[k], op)
+            if stopped.any():
+                O.reset(planes, envs, seed=13, mask=stopped, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+                resets += int(stopped.sum())
+            np.testing.assert_array_equal(r[k], ro, err_msg=f"reward call {call} step {k}")
+            np.testing.assert_array_equal(d[k], do.astype(bool), err_msg=f"done call {call} step {k}")
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes call {call}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs call {call}")
+    assert resets > B // 2
+    env.close()
 
 
 # ---------------------------------------------------------------- consumers of the path
@@ -784,7 +958,7 @@ def test_api_edge_cases(wf):
         env.upload(None, ge2)
         _, r2, d2, _ = env.step(None)
         assert d2.all() and (r2 == 0).all()
-        np.testing.assert_array_equal(env.download()[0], gp if False else env.download()[0])
+        np.testing.assert_array_equal(env.download()[0], planes, err_msg="a scalars-only upload must leave the planes alone")
         env.close()
         env.close()                                      # idempotent
     # invalid device index / shapes
@@ -851,16 +1025,18 @@ def test_plain_c_client_matches_python_path(wf, tmp_path):
 
 
 def test_bench_contract_single_and_two_ranks(wf):
-    """bench.py as the driver runs it: one JSON line with the contract's keys; the N = 2 launch through
-    torch.distributed.run (two ranks sharing this box's one GPU -> gloo carries the barrier) shards the
-    global batch and reports the whole-job rate."""
+    """bench.py as the driver runs it: one JSON line with the contract's keys, extra config legs with their own
+    rooflines; `--gpus 2` on this one-GPU box is refused loudly; the N = 2 launch through torch.distributed.run
+    with --share-gpu (two ranks on this box's one GPU -> gloo carries the barrier, labelled shared_card) shards
+    the global batch and reports the whole-job rate; a WORLD_SIZE that contradicts --gpus is an error."""
     import json
     import os
     import subprocess
     import sys
+    import torch
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(repo, "bench.py"), "--steps", "30", "--warmup", "5", "--batch", "16384", "--no-cpu-baseline"]
-    r1 = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, timeout=300, cwd=repo)
+    r1 = subprocess.run(base + ["--gpus", "1", "--legs", "c2,c4"], capture_output=True, text=True, timeout=300, cwd=repo)
     assert r1.returncode == 0, r1.stderr[-2000:]
     lines = [l for l in r1.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r1.stdout
@@ -870,14 +1046,33 @@ def test_bench_contract_single_and_two_ranks(wf):
         assert k in d1, k
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d1["roofline"], k
-    assert d1["n_gpus"] == 1 and d1["steps"] == 30 and d1["scaling"] == "weak" and d1["vs_baseline"] is None
+    assert d1["n_gpus"] == 1 and d1["scaling"] == "weak" and d1["vs_baseline"] is None
+    # 30 steps are far below the minimum duration of the timed region: repeated, and said so
+    assert d1["steps_requested"] == 30 and d1["steps"] % 30 == 0 and d1["steps"] * d1["ms_per_step"] >= 45.0
     assert abs(d1["roofline"]["frac"] - d1["roofline"]["achieved"] / d1["roofline"]["peak"]) < 1e-9
+    assert "custom size" in d1["config"]["workload"] and "configs[2]" not in d1["config"]["workload"]
+    for leg, tag in (("c2", "configs[1]"), ("c4", "configs[3]")):
+        assert tag in d1["configs"][leg]["workload"] and 0 < d1["configs"][leg]["roofline"]["frac"] < 1.2, d1["configs"][leg]
+    assert d1["configs"]["c4"]["roofline"]["kernel"] == "wf_step_tiled"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=repo, env=env)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-500:])
+    r = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=repo,
+                       env=dict(env, WORLD_SIZE="4", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29533"] + base[1:] + ["--gpus", "2"],
+                         "--master-addr", "127.0.0.1", "--master-port", "29533"] + base[1:] + ["--gpus", "2", "--share-gpu", "--no-extras"],
                         capture_output=True, text=True, timeout=400, cwd=repo, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
     lines = [l for l in r2.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r2.stdout
     d2 = json.loads(lines[0])
     assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 2 * 16384 and d2["value"] > 0
+    assert d2["shared_card"] is True and d2["rccl_ranks"] is None
+    # the same through bench.py's own per-GPU launcher (no torchrun)
+    r3 = subprocess.run(base + ["--gpus", "2", "--share-gpu", "--no-extras"], capture_output=True, text=True, timeout=400, cwd=repo, env=env)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    d3 = json.loads([l for l in r3.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d3["n_gpus"] == 2 and d3["config"]["global_batch"] == 2 * 16384

@@ -211,3 +211,28 @@ def test_plain_c_client_builds_and_fails_loudly_without_device(tmp_path):
     exe = build_native_example(tmp_path)
     r = subprocess.run([exe, "8", "1"], capture_output=True, text=True)
     assert r.returncode == 2 and "no usable HIP device" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_bench_gpus_flag_is_loud():
+    """`--gpus N` means N ranks on N GPUs: without them (no launcher, too few devices) or with a WORLD_SIZE that
+    says otherwise, bench.py exits non-zero with a message instead of quietly benchmarking one GPU."""
+    if _has_gpu():
+        pytest.skip("device-count refusal is covered by the GPU bench test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "--gpus 2 but only 0 GPU(s) visible" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_labels_name_the_config_they_are():
+    import bench
+    assert bench.config_label(14, 65536, False, 0) == "BASELINE configs[2]"
+    assert bench.config_label(10, 4096, True, 0) == "BASELINE configs[1]"
+    assert bench.config_label(256, 1024, True, 10000) == "BASELINE configs[3]"
+    assert "configs[4]" in bench.config_label(14, 125000, False, 0)
+    assert bench.config_label(14, 16384, False, 0) == "custom size"
+    ref = bench.reference_python_numbers(14)      # written by tools/time_reference.py from the real reference
+    assert ref and ref["grid"] == 14 and 1e5 < ref["cell_updates_per_s_1_process"] < 1e8

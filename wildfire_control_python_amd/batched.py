@@ -117,6 +117,12 @@ class BatchedForestFire:
     def sync(self):
         self._ck(self._lib.wf_sync(self._h), "wf_sync")
 
+    def reload_env(self):
+        """Experiments / tests: re-read the WF_* environment switches (they are cached at construction)."""
+        self._ck(self._lib.wf_reload_env(self._h), "wf_reload_env")
+        self.step_kernel = self._lib.wf_step_kernel_name(self._h).decode()
+        self.step_launches = int(self._lib.wf_step_launches(self._h))
+
     @property
     def planes_ptr(self):
         return self._lib.wf_planes_device(self._h)

@@ -27,6 +27,7 @@ struct wf_ctx {
     hipStream_t side[WF_MAX_SIDE] = {};
     hipEvent_t ev_side[WF_MAX_SIDE] = {}, ev_fork = nullptr;
     int n_parts = 2;                  // launches per step (WF_SPLIT overrides, 1 = never split)
+    WfKnobs knobs = {};               // WF_* experiment switches, read once (wf_create / wf_reload_env)
     bool side_pending = false;        // work enqueued on `side` that `stream` has not waited for yet
     bool main_touched = true;         // non-step work enqueued on `stream` since the last fork
     // device state
@@ -115,10 +116,7 @@ WfArgs base_args(const wf_ctx *c)
     a.ignite_count = c->p.ignite_count;
     a.hot_flags = (c->p.containment ? WF_HOT_CONTAINMENT : 0) | (c->p.auto_reset ? WF_HOT_AUTO_RESET : 0) |
                   (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0);
-    {   // experiment knob: cap on environments per wave of the single-step kernel
-        const char *g = getenv("WF_GROUP");
-        a.group = g ? atoi(g) : 0;
-    }
+    a.group = c->knobs.group;          // experiment knob: cap on environments per wave of the single-step kernel
     a.default_reward = c->p.default_reward;
     a.death_penalty = c->p.death_penalty;
     a.contained_bonus = c->p.contained_bonus;
@@ -148,16 +146,15 @@ int join_side(wf_ctx *c)
 // A single step of a large batch on the context's OWN streams goes out as n_parts concurrent launches.
 bool splits(const wf_ctx *c, int n_steps)
 {
-    const char *m = getenv("WF_SPLIT_MIN");                  // experiment: smallest batch that is split
-    const int min_batch = m ? atoi(m) : 4096 * c->n_parts;   // 8 192 envs: 7.9 vs 9.6 us per step; 4 096: 7.4 vs 6.8
+    const int min_batch = c->knobs.split_min > 0 ? c->knobs.split_min : 4096 * c->n_parts;   // 8 192 envs: 7.9 vs 9.6 us per step; 4 096: 7.4 vs 6.8
     return c->fam == WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && n_steps == 1 && c->batch >= min_batch &&
-           !getenv("WF_NO_SPLIT");
+           !c->knobs.no_split;
 }
 
 bool splits_big(const wf_ctx *c)
 {
     return c->fam != WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && c->batch >= 2 * c->n_parts &&
-           (size_t)c->batch * c->H * c->W >= ((size_t)8 << 20) && !getenv("WF_NO_SPLIT");
+           (size_t)c->batch * c->H * c->W >= ((size_t)8 << 20) && !c->knobs.no_split;
 }
 
 // (re)publish the rarely needed parameters to the device
@@ -169,6 +166,17 @@ int push_cold(wf_ctx *c)
     h.spawn = c->spawn;
     HIP_TRY(c, hipMemcpy(c->d_cold, &h, sizeof(h), hipMemcpyHostToDevice));
     return WF_OK;
+}
+
+// Is an n_steps call of this (split) context served by the rows kernel's own step loop?  Probed with the FIRST part's
+// shape (the largest one); every part then runs the same kernel.
+bool multi_rows_call(const wf_ctx *c, int n_steps)
+{
+    WfArgs probe = base_args(c);
+    probe.n_steps = n_steps;
+    probe.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+    if (probe.group <= 0) probe.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);
+    return wf_multi_step_in_rows(c->fam, probe, c->knobs, c->num_cus);
 }
 
 int ensure_staging(wf_ctx *c, int n_steps)
@@ -269,7 +277,8 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         c->own_stream = true;
         if ((e = hipEventCreate(&c->ev0)) != hipSuccess) break;
         if ((e = hipEventCreate(&c->ev1)) != hipSuccess) break;
-        if (const char *sp = getenv("WF_SPLIT")) c->n_parts = atoi(sp) < 1 ? 1 : atoi(sp) > WF_MAX_SIDE + 1 ? WF_MAX_SIDE + 1 : atoi(sp);
+        wf_read_knobs(&c->knobs);
+        c->n_parts = c->knobs.n_parts < 1 ? 1 : c->knobs.n_parts > WF_MAX_SIDE + 1 ? WF_MAX_SIDE + 1 : c->knobs.n_parts;
         for (int i = 0; i < c->n_parts - 1 && e == hipSuccess; ++i) {
             if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) break;
             e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming);
@@ -429,14 +438,11 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
         // Large batches: one launch per stream whose waves step their environments n_steps times (shapes with a
         // rows-layout kernel), else n_steps single-step launches; both beat the fused one-environment-per-wave
         // kernel there (4.2e11 cell-updates/s at 65 536 x 14x14), which serves small, launch-bound batches.
-        bool in_kernel = false;
-        if (n_steps > 1 && splits(c, 1)) {
-            WfArgs probe = base_args(c);
-            probe.n_steps = n_steps;
-            probe.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
-            if (probe.group <= 0) probe.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);
-            in_kernel = wf_multi_step_in_rows(c->fam, probe, c->num_cus);
-        }
+        // The verdict is reached ONCE, from the shape of the whole call, and handed to every part launch
+        // (WfKnobs::multi_rows): a ragged last part must not fall back to another kernel on its own.
+        const bool in_kernel = n_steps > 1 && splits(c, 1) && multi_rows_call(c, n_steps);
+        WfKnobs kn = c->knobs;
+        kn.multi_rows = in_kernel ? 1 : 0;
         const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
         const int n_launch = each ? n_steps : 1;
         const size_t cells = (size_t)c->H * c->W;
@@ -452,7 +458,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             const bool split = splits(c, in_kernel ? 1 : a.n_steps);
             if (!split) {
                 JOIN(c);
-                HIP_TRY(c, wf_launch_step(c->fam, a, c->stream, c->num_cus));
+                HIP_TRY(c, wf_launch_step(c->fam, a, kn, c->stream, c->num_cus));
                 continue;
             }
             // independent parts of the batch on separate streams (inputs must be complete when this is
@@ -463,7 +469,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
                 c->main_touched = false;
             }
             const int per = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
-            if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);   // as for the whole batch
+            if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);   // as for the whole batch
             for (int i = 0; i < c->n_parts; ++i) {
                 const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
                 if (lo >= hi) break;
@@ -478,7 +484,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
                 if (a.reward) ai.reward = a.reward + lo;
                 if (a.done) ai.done = a.done + lo;
                 if (a.obs) ai.obs = a.obs + (size_t)lo * cells * 3;
-                HIP_TRY(c, wf_launch_step(c->fam, ai, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
+                HIP_TRY(c, wf_launch_step(c->fam, ai, kn, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
             }
             c->side_pending = true;
         }
@@ -623,10 +629,10 @@ const char *wf_step_kernel_name(const wf_ctx *c)
     if (!c) return "none";
     WfArgs a = base_args(c);
     if (splits(c, 1)) {
-        if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);
+        if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);
         a.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
     }
-    return wf_single_step_kernel(c->fam, a, c->num_cus);
+    return wf_single_step_kernel(c->fam, a, c->knobs, c->num_cus);
 }
 
 int wf_call_launches(const wf_ctx *c, int n_steps)
@@ -635,11 +641,22 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
     if (c->fam != WF_FAM_WAVE) return n_steps * (splits_big(c) ? c->n_parts : 1);      // launch sequences
     if (!splits(c, 1)) return n_steps == 1 ? 1 : 1;                                     // one (fused) launch
     if (n_steps == 1) return c->n_parts;
-    WfArgs probe = base_args(c);
-    probe.n_steps = n_steps;
-    probe.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
-    if (probe.group <= 0) probe.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch);
-    return wf_multi_step_in_rows(c->fam, probe, c->num_cus) ? c->n_parts : c->n_parts * n_steps;
+    return multi_rows_call(c, n_steps) ? c->n_parts : c->n_parts * n_steps;
+}
+
+int wf_reload_env(wf_ctx *c)
+{
+    if (!c) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int parts = c->n_parts;
+    wf_read_knobs(&c->knobs);
+    c->knobs.n_parts = parts;          // the side streams exist since wf_create: WF_SPLIT is fixed for a context's life
+    // boards are kept per kernel layout: a switch of kernels must not meet a board the other layout left stale
+    HIP_TRY(c, wf_launch_invalidate_reach(c->envs, c->batch, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
 }
 
 int wf_step_launches(const wf_ctx *c)

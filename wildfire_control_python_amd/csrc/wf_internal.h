@@ -52,6 +52,21 @@ struct WfArgs {
     double default_reward, death_penalty, contained_bonus;
 };
 
+// Experiment / test switches, read from the WF_* environment variables ONCE per context (wf_create; wf_reload_env
+// re-reads them) so that the launch path never calls getenv().
+struct WfKnobs {
+    int group;       // WF_GROUP: cap on environments per wave of the single-step kernel (0 = automatic)
+    int split_min;   // WF_SPLIT_MIN: smallest batch stepped as concurrent part launches (0 = automatic)
+    int no_split;    // WF_NO_SPLIT: one launch per step
+    int n_parts;     // WF_SPLIT: launches per step of a large batch (default 2)
+    int shared;      // WF_SHARED=N: workgroup-shared agent phases (N waves per workgroup; 1 = automatic)
+    int rows;        // WF_ROWS: keep the rows layout for group overrides beyond 16
+    int no_rows;     // WF_NO_ROWS: 4-cells-per-lane group layout only
+    int no_multi;    // WF_NO_MULTI: an n-step call of a large batch = n single-step launches
+    int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop
+};
+void wf_read_knobs(WfKnobs *k);
+
 // kernel families (wf_kernels.hip)
 enum WfFamily { WF_FAM_NONE = 0, WF_FAM_WAVE = 1, WF_FAM_TILED = 2, WF_FAM_CELLS = 3 };
 
@@ -72,12 +87,14 @@ static inline int wf_pick_group(int cells, int num_cus, long long batch)
 // The same, knowing the grid shape: shapes served by the rows-layout kernel keep G <= 8 - more, shorter waves than
 // resident slots beat longer waves at every batch from 131 072 up (75 vs 69 % of roofline at 131 072 x 14x14,
 // 80 vs 75 % at 262 144; a wash once the state outgrows the memory-side cache).
-int wf_pick_group_for(int W, int H, int num_cus, long long batch);
+int wf_pick_group_for(int W, int H, int num_cus, long long batch, const WfKnobs &k);
 
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
-const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus);
-bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, int num_cus);   // n_steps > 1 served by ONE launch of the rows kernel
-hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
+const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus);
+// n_steps > 1 served by ONE launch of the rows kernel (decided ONCE per call from the whole call's shape; the
+// verdict travels to the part launches in WfKnobs::multi_rows)
+bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus);
+hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus);
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 // big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out
 // halo != nullptr (tiled family): the step runs IN PLACE (planes_out == planes); halo = u64[batch][gx][8] scratch

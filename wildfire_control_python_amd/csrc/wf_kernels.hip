@@ -315,29 +315,25 @@ template <> struct HasRows<14, 14> { static constexpr bool value = true; static 
 template <> struct HasRows<10, 10> { static constexpr bool value = true; static constexpr int S = 2; };   // 5 cells/lane, 2 envs/iteration
 
 template <int W, int H>
-StepPlan plan_single(const WfArgs &a, int num_cus)
+StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
 {
     StepPlan p;
-    p.G = wf_pick_group_for(W, H, num_cus, a.batch);
+    p.G = wf_pick_group_for(W, H, num_cus, a.batch, k);
     const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
     if (a.group > 0) p.G = a.group < gmax ? a.group : gmax;
-    const bool shared = getenv("WF_SHARED") && (p.G == 8 || p.G == 16) && a.batch >= 4096;
+    const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096;
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
     if constexpr (HasRows<W, H>::value) {
         constexpr int EPW = RG<W, H, HasRows<W, H>::S>::EPW;
         // (wf_pick_group_for keeps G <= 16 for these shapes; an override beyond that needs WF_ROWS=1 to stay on rows)
-        if (p.G % EPW == 0 && (p.G <= 16 || (p.G <= 32 && getenv("WF_ROWS"))) && a.env_base % EPW == 0 && !getenv("WF_NO_ROWS"))
+        if (p.G % EPW == 0 && (p.G <= 16 || (p.G <= 32 && k.rows)) && a.env_base % EPW == 0 && !k.no_rows)
             p.kind = shared ? STEP_ROWS_SHARED : STEP_ROWS;
     }
     return p;
 }
 
-}  // namespace
-bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, int num_cus);
-namespace {
-
 template <int W, int H>
-hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
+hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus)
 {
     int blocks = (a.batch + 3) / 4;
     const int cap = num_cus * 8;            // up to 32 resident waves per CU
@@ -345,10 +341,11 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
     if (blocks < 1) blocks = 1;
     if (reset)
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.n_steps > 1 && !wf_multi_step_in_rows(WF_FAM_WAVE, a, num_cus))
+    else if (a.n_steps > 1 && !k.multi_rows)
         hipLaunchKernelGGL((wf_step_wave<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
     else {
-        const StepPlan p = plan_single<W, H>(a, num_cus);
+        const StepPlan p = plan_single<W, H>(a, k, num_cus);
+        if (a.n_steps > 1 && p.kind != STEP_ROWS) return hipErrorInvalidValue;   // only the rows kernel has the step loop
         WfArgs g = a;
         g.group = p.G;
         const int waves = (a.batch + p.G - 1) / p.G;
@@ -359,7 +356,7 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
             if (p.kind == STEP_ROWS && a.n_steps <= 1) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false>), grid_private, dim3(256), 0, s, g);
             if (p.kind == STEP_ROWS_SHARED) {
                 // WF_SHARED=N with N in {2,4,8}: N waves share the agent phases (N*G <= 64 environments per workgroup)
-                int nw = atoi(getenv("WF_SHARED"));
+                int nw = k.shared;
                 if (nw < 2 || nw * p.G > 64) nw = 64 / p.G;
                 const int per_wg = nw * p.G;
                 hipLaunchKernelGGL((wf_step_rows<W, H, S, true, false>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
@@ -373,9 +370,9 @@ hipError_t launch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
 
 #define WF_WAVE_SHAPES(X) X(8, 8) X(10, 10) X(12, 12) X(14, 14) X(16, 16) X(16, 8) X(8, 16) X(20, 10) X(10, 20)
 
-hipError_t dispatch_wave(bool reset, const WfArgs &a, hipStream_t s, int num_cus)
+hipError_t dispatch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus)
 {
-#define X(w, h) if (a.W == w && a.H == h) return launch_wave<w, h>(reset, a, s, num_cus);
+#define X(w, h) if (a.W == w && a.H == h) return launch_wave<w, h>(reset, a, k, s, num_cus);
     WF_WAVE_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
@@ -392,14 +389,29 @@ WfFamily wf_pick_family(int H, int W)
     return WF_FAM_CELLS;
 }
 
-int wf_pick_group_for(int W, int H, int num_cus, long long batch)
+void wf_read_knobs(WfKnobs *k)
+{
+    auto num = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+    auto set = [](const char *name) { return getenv(name) != nullptr; };
+    k->group = num("WF_GROUP", 0);
+    k->split_min = num("WF_SPLIT_MIN", 0);
+    k->no_split = set("WF_NO_SPLIT");
+    k->n_parts = num("WF_SPLIT", 2);
+    k->shared = set("WF_SHARED") ? (num("WF_SHARED", 1) > 1 ? num("WF_SHARED", 1) : 1) : 0;
+    k->rows = set("WF_ROWS");
+    k->no_rows = set("WF_NO_ROWS");
+    k->no_multi = set("WF_NO_MULTI");
+    k->multi_rows = 0;
+}
+
+int wf_pick_group_for(int W, int H, int num_cus, long long batch, const WfKnobs &k)
 {
     int G = wf_pick_group(W * H, num_cus, batch);
     bool rows = false;
 #define X(w, h) if (W == w && H == h) rows = HasRows<w, h>::value;
     WF_WAVE_SHAPES(X)
 #undef X
-    if (rows && !getenv("WF_NO_ROWS") && G > 8) G = 8;
+    if (rows && !k.no_rows && G > 8) G = 8;
     return G;
 }
 
@@ -415,25 +427,25 @@ const char *wf_family_name(WfFamily f, int, int)
 
 // Large batches of a shape with a rows-layout kernel: an n_steps call is ONE launch of that kernel, every wave
 // stepping its environments n_steps times (small batches: the fused one-environment-per-wave kernel).
-bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, int num_cus)
+bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus)
 {
-    if (fam != WF_FAM_WAVE || a.step_stride <= 0 || a.batch < 4096 || getenv("WF_NO_MULTI")) return false;
+    if (fam != WF_FAM_WAVE || a.step_stride <= 0 || a.batch < 4096 || k.no_multi) return false;
     StepPlan p = { 0, -1 };
-#define X(w, h) if (a.W == w && a.H == h) p = plan_single<w, h>(a, num_cus);
+#define X(w, h) if (a.W == w && a.H == h) p = plan_single<w, h>(a, k, num_cus);
     WF_WAVE_SHAPES(X)
 #undef X
     return p.kind == STEP_ROWS;
 }
 
 // symbol of the kernel that would serve a single step of `a` (introspection for bench / profiles)
-const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus)
+const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus)
 {
     static thread_local char buf[64];
     if (fam == WF_FAM_TILED) return "wf_step_tiled";
     if (fam == WF_FAM_CELLS) return "wf_step_cells";
     StepPlan p = { 0, -1 };
     int S = 1;
-#define X(w, h) if (a.W == w && a.H == h) { p = plan_single<w, h>(a, num_cus); S = HasRows<w, h>::S; }
+#define X(w, h) if (a.W == w && a.H == h) { p = plan_single<w, h>(a, k, num_cus); S = HasRows<w, h>::S; }
     WF_WAVE_SHAPES(X)
 #undef X
     if (p.kind < 0) return "none";
@@ -442,15 +454,15 @@ const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, int num_cus)
     return buf;
 }
 
-hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus)
+hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus)
 {
-    if (fam == WF_FAM_WAVE) return dispatch_wave(false, a, s, num_cus);
+    if (fam == WF_FAM_WAVE) return dispatch_wave(false, a, k, s, num_cus);
     return hipErrorInvalidValue;
 }
 
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus)
 {
-    if (fam == WF_FAM_WAVE) return dispatch_wave(true, a, s, num_cus);
+    if (fam == WF_FAM_WAVE) { WfKnobs k = {}; return dispatch_wave(true, a, k, s, num_cus); }
     return hipErrorInvalidValue;
 }
 

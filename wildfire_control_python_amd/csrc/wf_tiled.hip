@@ -397,7 +397,11 @@ __global__ __launch_bounds__(256) void wf_big_flood(const WfArgs a, const uint8_
         }
     }
     __syncthreads();
-    for (uint32_t it = 0; it < 4u * (H + W) * 4u; ++it) {
+    // A relaxation sweep advances the front by at least one cell along every shortest path, and a shortest path
+    // through passable cells has fewer than H*W cells (a serpentine between dirt walls comes close): H*W sweeps
+    // always suffice, like the wave and cell floods; a mere 4*(H+W) would not.
+    bool converged = false;
+    for (uint32_t it = 0; it < H * W; ++it) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
         bool ch = false;
@@ -412,12 +416,13 @@ __global__ __launch_bounds__(256) void wf_big_flood(const WfArgs a, const uint8_
         }
         if (ch) changed = 1;
         __syncthreads();
-        if (!changed) break;
+        if (!changed) { converged = true; break; }
         __syncthreads();
     }
     u64 *out = a.reach + (size_t)e * words;
     for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = reach[k];
-    if (threadIdx.x == 0) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
+    // (never true with the H*W bound; kept so that a board that did not converge could not be trusted later)
+    if (threadIdx.x == 0 && converged) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
 }
 
 // ---------------------------------------------------------------------------- flood, generic family

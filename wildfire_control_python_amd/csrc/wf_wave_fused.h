@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
 
         const int n_steps = FUSED ? a.n_steps : 1;
         for (int st = 0; st < n_steps; ++st) {
-            const uint32_t oi = (uint32_t)st * batch + e;
+            const uint32_t oi = (uint32_t)st * (uint32_t)a.step_stride + e;       // row st of the (n_steps, context batch) arrays
             uint32_t act_next = 0xffu;
             if (FUSED) {
-                if (st + 1 < n_steps && a.actions) act_next = (uint32_t)(uint8_t)a.actions[oi + batch];
+                if (st + 1 < n_steps && a.actions) act_next = (uint32_t)(uint8_t)a.actions[oi + (uint32_t)a.step_stride];
             }
             reward = 0.0;
             done = 1;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                     uint32_t e_pin = e;
                     asm volatile("" : "+s"(cold), "+s"(e_pin));
                     cold_ptr cc = (cold_ptr)(uintptr_t)cold;
-                    reset_regs<W, H>(cold, cc->p.seed, e_pin, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
+                    reset_regs<W, H>(cold, cc->p.seed, e_pin + a.env_base, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);   // stream keyed by the context index
                     ax = s.ax; ay = s.ay; fl = s.fl; episode = s.episode; tick = s.tick;
                     {   // the fresh bitboards were written with vector stores: keep them in registers,
                         // never re-read them through the scalar cache inside this launch
