@@ -24,7 +24,8 @@
  *   planes  int8 (batch, H, W, 4) C-contiguous; H <-> y, W <-> x (the reference
  *           indexes env[x, y, layer], environment.py:38-50; the transpose happens
  *           only in wf_get_state).  One 32-bit word per cell:
- *             plane 0 type   0 grass 1 fire 2 burnt 3 dirt 4 water (utility.py:128-140)
+ *             plane 0 type   0 grass 1 fire 2 burnt 3 dirt 4 water (utility.py:128-140);
+                            5 / 6 only with allow_dig_toggle, see WF_DIRT_BURNING below
  *             plane 1 fuel   (utility.py:99; reduce_fuel environment.py:297-307)
  *             plane 2 heat   number of heat quanta received = temp / (wind_speed*heat)
  *                            (environment.py:286-290); WF_HEAT_FORCED marks
@@ -50,7 +51,14 @@ extern "C" {
 #define WF_ABI_VERSION 1
 
 enum { WF_P_TYPE = 0, WF_P_FUEL = 1, WF_P_HEAT = 2, WF_P_AGENT = 3 };
-enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4 };
+enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4,
+       /* Two states only allow_dig_toggle can produce: toggle_digging() on a BURNING cell runs dig()
+        * (environment.py:123-138), which retypes the cell to dirt and blocks it (fire_mobility inf) but leaves
+        * it in World.burning_cells: it keeps losing fuel and heating its neighbours, shows as dirt (is_burning()
+        * false), and when its fuel is gone reduce_fuel() (:297-307) retypes it to burnt, still blocked.
+        * "Burning" everywhere in this library is (type & 3) == 1, i.e. WF_FIRE or WF_DIRT_BURNING. */
+       WF_DIRT_BURNING = 5,     /* reference: type dirt, member of burning_cells, fire_mobility inf */
+       WF_BURNT_BLOCKED = 6 };  /* reference: type burnt, fire_mobility inf (dig() turns it into WF_DIRT) */
 #define WF_HEAT_FORCED 25
 
 /* wf_env.flags */

@@ -123,6 +123,11 @@ typedef struct {
      * happens only here, at decode/encode) */
     double *type, *temp, *fuel;
     int8_t *agent_pos;
+    /* fire_mobility layer as a flag: 1 = inf (dirt, water, and whatever dig() blocked; environment.py:85,133).
+     * Not a function of `type` alone: Agent.dig() on a BURNING cell (toggle_digging, :136-138) retypes it to
+     * dirt but leaves it in burning_cells, and reduce_fuel() later retypes it to burnt with the mobility still inf. */
+    uint8_t *fmob_inf;
+    uint8_t *in_burning;     /* scratch: membership flags of burning_cells (encode) */
     /* World.burning_cells (environment.py:202): list of cell indices */
     int *burning;
     int n_burning;
@@ -170,8 +175,11 @@ static void dig(world *w)                                    /* environment.py:1
 {
     if (w->digging) {
         int c = w->ay * w->W + w->ax;
-        if (w->type[c] != WFO_DIRT)
-            w->type[c] = WFO_DIRT;   /* gray / fire_mobility are functions of type */
+        if (w->type[c] != WFO_DIRT) {
+            w->type[c] = WFO_DIRT;   /* :129 */
+            w->fmob_inf[c] = 1;      /* :133 fire_mobility = inf.  burning_cells is NOT touched: a cell that was
+                                      * burning keeps burning (fuel, radiation) under its new type */
+        }
     }
 }
 
@@ -285,8 +293,8 @@ static int fire_reaches_border(world *w)
             if (!inbounds(w, nx, ny))
                 continue;
             n = ny * W + nx;
-            if (w->seen[n] || w->type[n] == WFO_DIRT || w->type[n] == WFO_WATER)
-                continue;                                    /* fire_mobility == inf */
+            if (w->seen[n] || w->fmob_inf[n])
+                continue;                                    /* fire_mobility == inf (weights of astar_path, :353-356) */
             w->seen[n] = 1;
             w->queue[tail++] = n;
         }
@@ -327,16 +335,18 @@ static int world_alloc(world *w, int H, int W, const wfo_params *p)
     w->temp = malloc(n * sizeof(double));
     w->fuel = malloc(n * sizeof(double));
     w->agent_pos = malloc(n);
+    w->fmob_inf = malloc(n);
+    w->in_burning = malloc(n);
     w->burning = malloc(n * sizeof(int));
     w->queue = malloc(n * sizeof(int));
     w->seen = malloc(n);
     w->quantum = p->wind_speed * p->heat * pow(0.0 + 1.0, -1.0);
-    return w->type && w->temp && w->fuel && w->agent_pos && w->burning && w->queue && w->seen;
+    return w->type && w->temp && w->fuel && w->agent_pos && w->fmob_inf && w->in_burning && w->burning && w->queue && w->seen;
 }
 
 static void world_free(world *w)
 {
-    free(w->type); free(w->temp); free(w->fuel); free(w->agent_pos);
+    free(w->type); free(w->temp); free(w->fuel); free(w->agent_pos); free(w->fmob_inf); free(w->in_burning);
     free(w->burning); free(w->queue); free(w->seen);
 }
 
@@ -356,11 +366,15 @@ static void decode(world *w, const int8_t *pl, const wfo_env *e)
     int n = w->W * w->H, i;
     w->n_burning = 0;
     for (i = 0; i < n; ++i) {
-        w->type[i] = pl[4 * i + WFO_P_TYPE];
+        int t = pl[4 * i + WFO_P_TYPE];
+        /* boundary codes 5 / 6 (see wf_oracle.h): reference type dirt + member of burning_cells / reference
+         * type burnt + fire_mobility inf */
+        w->type[i] = t == WFO_DIRT_BURNING ? WFO_DIRT : t == WFO_BURNT_BLOCKED ? WFO_BURNT : t;
+        w->fmob_inf[i] = t >= WFO_DIRT;
         w->fuel[i] = pl[4 * i + WFO_P_FUEL];
         w->temp[i] = temp_from_count(w, pl[4 * i + WFO_P_HEAT]);
         w->agent_pos[i] = pl[4 * i + WFO_P_AGENT];
-        if (w->type[i] == WFO_FIRE)
+        if (t == WFO_FIRE || t == WFO_DIRT_BURNING)
             w->burning[w->n_burning++] = i;
     }
     w->ax = e->x;
@@ -377,8 +391,15 @@ static void decode(world *w, const int8_t *pl, const wfo_env *e)
 static void encode(const world *w, int8_t *pl, wfo_env *e)
 {
     int n = w->W * w->H, i;
+    memset(w->in_burning, 0, (size_t)n);
+    for (i = 0; i < w->n_burning; ++i)
+        if (w->burning[i] >= 0)
+            w->in_burning[w->burning[i]] = 1;
     for (i = 0; i < n; ++i) {
-        pl[4 * i + WFO_P_TYPE] = (int8_t)w->type[i];
+        int t = (int)w->type[i];
+        if (t == WFO_DIRT && w->in_burning[i]) t = WFO_DIRT_BURNING;
+        if (t == WFO_BURNT && w->fmob_inf[i]) t = WFO_BURNT_BLOCKED;
+        pl[4 * i + WFO_P_TYPE] = (int8_t)t;
         pl[4 * i + WFO_P_FUEL] = (int8_t)w->fuel[i];
         pl[4 * i + WFO_P_HEAT] = (int8_t)lrint(w->temp[i] / w->quantum);
         pl[4 * i + WFO_P_AGENT] = w->agent_pos[i];
@@ -468,6 +489,7 @@ int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
             w.type[i] = 0;
             w.temp[i] = 0;
             w.agent_pos[i] = 0;
+            w.fmob_inf[i] = 0;                               /* :64 fire_mobility.fill(1) */
             if (p->fuel_lo == p->fuel_hi)
                 w.fuel[i] = p->fuel_lo;                      /* :63 grass['fuel'] */
             else
@@ -524,7 +546,7 @@ int wfo_get_state(int batch, int H, int W, const int8_t *planes, int8_t *obs)
                 int8_t *d = o + 3 * (x * H + y);             /* environment.py:399-402, [x][y][k] */
                 d[0] = c[WFO_P_AGENT];
                 d[1] = (int8_t)(c[WFO_P_TYPE] == WFO_FIRE);
-                d[2] = (int8_t)(c[WFO_P_TYPE] != WFO_DIRT && c[WFO_P_TYPE] != WFO_WATER);
+                d[2] = (int8_t)(c[WFO_P_TYPE] < WFO_DIRT);   /* fire_mobility != inf: not dirt / water / codes 5, 6 */
             }
     }
     return 0;

@@ -35,7 +35,14 @@ extern "C" {
 #endif
 
 enum { WFO_P_TYPE = 0, WFO_P_FUEL = 1, WFO_P_HEAT = 2, WFO_P_AGENT = 3 };
-enum { WFO_GRASS = 0, WFO_FIRE = 1, WFO_BURNT = 2, WFO_DIRT = 3, WFO_WATER = 4 };
+enum { WFO_GRASS = 0, WFO_FIRE = 1, WFO_BURNT = 2, WFO_DIRT = 3, WFO_WATER = 4,
+       /* Two states the reference can only reach with allow_dig_toggle (forest_fire.py:35-36): toggle_digging() on
+        * a BURNING cell runs dig() (environment.py:123-138), which retypes the cell to dirt and sets its
+        * fire_mobility to inf but leaves it in World.burning_cells.  The cell keeps losing fuel and radiating heat
+        * under type dirt (is_burning() false: the agent on it survives, the observation shows dirt), and when its
+        * fuel runs out reduce_fuel() retypes it to burnt with the mobility still inf. */
+       WFO_DIRT_BURNING = 5,    /* reference: type dirt, in burning_cells, fire_mobility inf  */
+       WFO_BURNT_BLOCKED = 6 }; /* reference: type burnt, fire_mobility inf                    */
 
 enum {
     WFO_F_ALIVE     = 1,   /* World.agents non-empty (environment.py:206-208)            */

@@ -125,13 +125,24 @@ class Recorder:
                 continue
             assert t == self._seqsum(v), (x, y, t, v)
         p = np.zeros((self.size, self.size, 4), dtype=np.int8)  # [y, x, plane]
-        p[:, :, P_TYPE] = env[:, :, L["type"]].T
+        code = env[:, :, L["type"]].astype(np.int64)         # [x, y]
+        fm = env[:, :, L["fire_mobility"]]
+        # Two states only allow_dig_toggle can produce (toggle_digging -> dig() on a burning cell,
+        # environment.py:123-138): type dirt but still a member of burning_cells -> boundary code 5; and, once
+        # its fuel is gone (reduce_fuel :297-307), type burnt with fire_mobility still inf -> code 6.
+        for (x, y) in W.burning_cells:
+            if code[x, y] == 3:
+                code[x, y] = 5
+            else:
+                assert code[x, y] == 1, (x, y, code[x, y])
+        code[(code == 2) & np.isinf(fm)] = 6
+        assert set(zip(*np.nonzero((code == 1) | (code == 5)))) == {(int(x), int(y)) for x, y in W.burning_cells}
+        # fire_mobility is a pure function of the boundary code (environment.py:85,133)
+        assert np.array_equal(np.isinf(fm), code >= 3)
+        p[:, :, P_TYPE] = code.T
         p[:, :, P_FUEL] = env[:, :, L["fuel"]].T
         p[:, :, P_HEAT] = q.T
         p[:, :, P_AGENT] = env[:, :, L["agent_pos"]].T
-        # derived layers are pure functions of type (environment.py:85,133)
-        fm = env[:, :, L["fire_mobility"]]
-        assert np.array_equal(np.isinf(fm), env[:, :, L["type"]] >= 3)
         return p
 
     def _agent(self):
@@ -313,6 +324,52 @@ def run_size(size):
         ep += 1
     constants.METADATA["make_rivers"] = False
     rec.save(out("river"))
+
+    # 7. allow_dig_toggle (forest_fire.py:35-36): action 4 toggles dig mode.  Odd episodes are scripted so that the
+    #    agent toggles digging ON while standing on a BURNING cell - the reference then holds a dirt cell that keeps
+    #    burning (codes 5 / 6 above): dig mode off, walk next to the fire, wait until the own cell ignites, toggle.
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(6000 + size)
+    constants.METADATA["allow_dig_toggle"] = True
+    zombies = 0
+    for ep in range(20):
+        reset(600 + ep)
+        if ep % 4 == 3:
+            sim.W.env[:, :, layer["fuel"]] = rng.integers(4, 31, size=(size, size)).astype(np.float64)
+        rec.begin()
+        done, phase, t = False, 0, 0
+        while not done:
+            ag = sim.W.agents[0] if sim.W.agents else None
+            if ep % 2 == 0 or ag is None:
+                a = int(rng.integers(0, 5))
+            elif phase == 0:                       # dig mode off
+                a, phase = 4, 1
+            elif phase == 1:                       # approach: stand on a grass cell next to the fire
+                fx, fy = size // 2, size // 2
+                opts = [d for d in range(4) if not ag.fire_in_direction(d)]
+                best = [d for d in opts
+                        if abs(ag._direction_to_coords(d)[0] - fx) + abs(ag._direction_to_coords(d)[1] - fy)
+                        < abs(ag.x - fx) + abs(ag.y - fy)]
+                near = any(ag.fire_in_direction(d) for d in range(4))
+                if near and sim.W.is_burnable((ag.x, ag.y)):
+                    a, phase = NOOP, 2
+                else:
+                    a = int(rng.choice(best)) if best else (int(rng.choice(opts)) if opts else NOOP)
+            elif phase == 2:                       # wait for the own cell to ignite, then toggle digging on
+                if sim.W.is_burning((ag.x, ag.y)):
+                    a, phase = 4, 3
+                    zombies += 1
+                else:
+                    a = NOOP if sim.W.is_burnable((ag.x, ag.y)) else int(rng.integers(0, 4))
+            else:                                  # afterwards: wander, toggling now and then
+                a = int(rng.integers(0, 5)) if t % 3 else NOOP
+            _, _, done = rec.step(a)
+            t += 1
+    constants.METADATA["allow_dig_toggle"] = False
+    assert zombies >= 4, zombies
+    seen = np.asarray(rec.rows["planes"])[..., P_TYPE]
+    assert (seen == 5).any() and (seen == 6).any(), "the toggle fixture must contain burning-dirt and blocked-burnt cells"
+    rec.save(out("toggle"))
 
 
 def main():

@@ -35,7 +35,8 @@ def _envs(ge):
 @pytest.mark.parametrize("path", fixture_files(), ids=lambda p: p.split("/")[-1])
 def test_hip_reproduces_reference(wf, path):
     ep = Episodes(path)
-    env = wf.BatchedForestFire(ep.B, size=ep.size)
+    md = {"allow_dig_toggle": True, "n_actions": 5} if "toggle" in path else None     # constants.py:46 as the generator set it
+    env = wf.BatchedForestFire(ep.B, size=ep.size, metadata=md)
     env.upload(ep.init_planes, ep.init_envs)
     n_contained = 0
     for t in range(ep.T):
@@ -386,29 +387,90 @@ def test_a_speed_two_updates_every_other_step(wf):
     env.close()
 
 
-def test_dig_toggle_matches_oracle_outside_documented_corner(wf):
-    """allow_dig_toggle (forest_fire.py:35-36).  The one documented divergence - toggling
-    digging ON while standing on a burning cell - is excluded from the comparison."""
-    B = 512
-    env = wf.BatchedForestFire(B, size=10, metadata={"allow_dig_toggle": True, "n_actions": 5})
+def _toggle_script_actions(planes, envs, phase, rng):
+    """Host-side scripted agents (test only) that provoke dig() on a BURNING cell: dig mode off, walk next to
+    the fire, wait on a grass cell until it ignites under the agent, then toggle digging on (action 4)."""
+    B, H, W, _ = planes.shape
+    a = np.full(B, 5, dtype=np.int8)
+    DX, DY = (0, 0, 1, -1), (-1, 1, 0, 0)
+    for i in range(B):
+        fl, x, y = int(envs["flags"][i]), int(envs["x"][i]), int(envs["y"][i])
+        if phase[i] == 4 and (fl & O.F_ALIVE):               # after the dig on fire: close a ring around the fire
+            a[i] = _circle_actions(envs[i:i + 1], W, H, rng)[0] if rng.random() < 0.9 else rng.integers(0, 6)
+            continue
+        if (fl & (O.F_ALIVE | O.F_RUNNING)) != (O.F_ALIVE | O.F_RUNNING) or phase[i] >= 3:
+            a[i] = rng.integers(0, 6)
+            continue
+        t = planes[i, :, :, 0]
+        burning_nb = [d for d in range(4) if 0 <= x + DX[d] < W and 0 <= y + DY[d] < H and t[y + DY[d], x + DX[d]] == 1]
+        if phase[i] == 0:
+            a[i], phase[i] = (4, 1) if fl & O.F_DIGGING else (5, 1)
+        elif t[y, x] == 1:                                   # the cell under the agent burns: dig it (toggle on)
+            a[i], phase[i] = 4, 3 + (i % 2)
+        elif t[y, x] == 0 and burning_nb:
+            a[i] = 5                                         # wait for the own cell to ignite
+        else:
+            fy, fx = np.nonzero(t == 1)
+            if len(fx) == 0:
+                a[i] = rng.integers(0, 4)
+                continue
+            k = np.argmin(np.abs(fx - x) + np.abs(fy - y))
+            opts = [d for d in range(4) if d not in burning_nb and 0 <= x + DX[d] < W and 0 <= y + DY[d] < H
+                    and abs(fx[k] - x - DX[d]) + abs(fy[k] - y - DY[d]) < abs(fx[k] - x) + abs(fy[k] - y)]
+            a[i] = opts[rng.integers(len(opts))] if opts else rng.integers(0, 4)
+    return a
+
+
+@pytest.mark.parametrize("variant", ["group", "rows", "fused", "tiled", "cells"])
+def test_dig_toggle_matches_oracle_including_dig_on_a_burning_cell(wf, monkeypatch, variant):
+    """allow_dig_toggle (forest_fire.py:35-36, Agent.toggle_digging environment.py:136-138), bit-exact in every
+    kernel family - including the corner the reference reaches when digging is toggled ON over a burning cell: the
+    cell becomes dirt but stays in burning_cells (boundary code 5), keeps burning and radiating, ends as blocked
+    burnt (code 6).  Half of the agents act at random (actions 0..5), half are scripted to provoke it."""
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED", "WF_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    if variant == "rows":
+        monkeypatch.setenv("WF_GROUP", "2")
+    W, H = {"tiled": (24, 16), "cells": (11, 13)}.get(variant, (10, 10))
+    B, T = 384, 130
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=21, containment=True, fuel_range=(12, 30),
+                               metadata={"allow_dig_toggle": True, "n_actions": 5})
+    if variant in ("group", "rows"):
+        assert env.step_kernel.startswith("wf_step_" + variant), env.step_kernel
     env.reset(seed=21)
-    op = O.default_params(allow_dig_toggle=1)
-    planes, envs = O.new_state(B, 10, 10)
+    op = O.default_params(allow_dig_toggle=1, containment=1, fuel_lo=12, fuel_hi=30)
+    planes, envs = O.new_state(B, H, W)
     O.reset(planes, envs, seed=21, params=op)
     rng = np.random.default_rng(2)
-    ok = np.ones(B, dtype=bool)
-    for t in range(120):
-        a = rng.integers(0, 5, size=B).astype(np.int8)
-        live = (envs["flags"] & (O.F_RUNNING | O.F_ALIVE)) == (O.F_RUNNING | O.F_ALIVE)
-        on_fire = planes[np.arange(B), envs["y"], envs["x"], 0] == 1
-        ok &= ~(live & (a == 4) & ((envs["flags"] & O.F_DIGGING) == 0) & on_fire)
-        _, r, d, _ = env.step(a)
-        ro, do = O.step(planes, envs, a, op)
+    phase = np.zeros(B, dtype=np.int64)
+    phase[B // 2:] = 3                                           # second half: random actions throughout
+    seen5 = seen6 = paid = 0
+    t = 0
+    while t < T:
+        n = 3 if variant == "fused" else 1
+        acts = np.empty((n, B), dtype=np.int8)
+        oracle_out = []
+        for k in range(n):                                       # the script reads the ORACLE's state, step by step
+            acts[k] = _toggle_script_actions(planes, envs, phase, rng)
+            oracle_out.append(O.step(planes, envs, acts[k], op))
+        if variant == "fused":
+            r, d = env.step_many(acts)
+        else:
+            obs, r1, d1, _ = env.step(acts[0])
+            r, d = r1[None], d1[None]
+            np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        for k in range(n):
+            np.testing.assert_array_equal(r[k], oracle_out[k][0], err_msg=f"reward t={t + k}")
+            np.testing.assert_array_equal(d[k], oracle_out[k][1].astype(bool), err_msg=f"done t={t + k}")
         gp, ge = env.download()
-        np.testing.assert_array_equal(gp[ok], planes[ok], err_msg=f"planes t={t}")
-        np.testing.assert_array_equal(_envs(ge)[ok], envs[ok], err_msg=f"envs t={t}")
-        np.testing.assert_array_equal(r[ok], ro[ok])
-    assert ok.sum() > B * 0.9
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        seen5 += int((planes[..., 0] == 5).sum())
+        seen6 += int((planes[..., 0] == 6).sum())
+        paid += int(sum((o[0] == 1000.0).sum() for o in oracle_out))
+        t += n
+    assert seen5 > 200 and seen6 > 200, (seen5, seen6)
+    np.testing.assert_array_equal(env.get_state(), O.get_state(planes))
     env.close()
 
 
@@ -654,7 +716,7 @@ def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
     op = O.default_params(fuel_lo=10, fuel_hi=40)
     planes, envs = O.new_state(B, S, S)
     O.reset(planes, envs, seed=1234, params=op)
-    for call in range(14):                                       # 224 ticks: every episode ends
+    for call in range(21):                                       # 336 ticks: every episode ends (the last one at tick 323)
         r, d = env.step_many(None, n)
         for k in range(n):
             ro, do = O.step(planes, envs, None, op)
@@ -812,6 +874,111 @@ def test_multi_step_split_with_a_ragged_last_part(wf, monkeypatch, B, split):
         np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs call {call}")
     assert resets > B // 2
     env.close()
+
+
+# ------------------------------------------------- the reference's own published numbers
+@pytest.mark.parametrize("size", [10, 14])
+def test_published_baseline_reward_is_reproduced(wf, size):
+    """Plots/results_first.txt:2,20: the clockwise random-walk baseline (DQN.py:286-389) earns 1130.2 (10x10) /
+    1151.4 (14x14) per episode on average over the reference's 100 000 episodes.  >= 131 072 episodes of the same
+    policy on the HIP environment (device reset, default fuel 20, containment on, episode ends on `done`) must
+    land within 4 standard errors of it: reset spawn law, move / dig / death, containment payment and the
+    burnt-out reward, end to end against numbers the reference's authors wrote down."""
+    from tests.policy_util import (REFERENCE_BASELINE_MEAN, baseline_tolerance, run_baseline_episodes)
+    B, rounds = 32768, 4
+    env = wf.BatchedForestFire(B, size=size, seed=99, containment=True)
+    rng = np.random.default_rng(size)
+    obs = [None]
+
+    def reset():
+        obs[0] = env.reset()
+
+    def state():
+        e = env.download_envs()
+        return e["x"], e["y"], (e["flags"] & 1) != 0, obs[0][..., 1].transpose(0, 2, 1) != 0
+
+    def step(a):
+        o, r, d, _ = env.step(a)
+        obs[0] = o
+        return r, d
+
+    totals, died = [], []
+    for _ in range(rounds):
+        t, dd, _ = run_baseline_episodes(reset, step, state, B, rng)
+        totals.append(t)
+        died.append(dd)
+    total, died = np.concatenate(totals), np.concatenate(died)
+    tol = baseline_tolerance(total.std(), len(total))
+    assert abs(total.mean() - REFERENCE_BASELINE_MEAN[size]) < tol, (total.mean(), REFERENCE_BASELINE_MEAN[size], tol)
+    assert 0.01 < died.mean() < 0.15
+    env.close()
+
+
+def test_adapter_runs_the_reference_baseline_loop(wf):
+    """The reference's baseline loop, statement for statement what DQN.collect_memories(perform_baseline=True) and
+    choose_randomwalk_action do (DQN.py:286-389), against the single-environment ForestFire adapter: sim.reset(),
+    sim.W.agents, .x/.y, agents[0].fire_in_direction(action), sim.step(action) -> [state, reward, done, {}]."""
+    from tests.policy_util import REFERENCE_BASELINE_MEAN
+    size = 10
+    sim = wf.ForestFire(size=size)
+    np.random.seed(3)
+    key_map = {"N": 0, "S": 1, "E": 2, "W": 3}
+    totals, deaths, avoided = [], 0, 0
+    for episode in range(400):
+        state = sim.reset()
+        assert state.shape == (size, size, 3)
+        done, total_reward = False, 0
+        while not done:
+            if not sim.W.agents:
+                action = 0
+            else:
+                width, height = sim.W.WIDTH, sim.W.HEIGHT
+                agent_x, agent_y = sim.W.agents[0].x, sim.W.agents[0].y
+                mid_x, mid_y = int(width / 2), int(height / 2)
+                count = 0
+                while True:
+                    if agent_x >= mid_x and agent_y > mid_y:
+                        possible_actions = ["S", "W"]
+                    if agent_x > mid_x and agent_y <= mid_y:
+                        possible_actions = ["S", "E"]
+                    if agent_x <= mid_x and agent_y < mid_y:
+                        possible_actions = ["N", "E"]
+                    if agent_x < mid_x and agent_y >= mid_y:
+                        possible_actions = ["N", "W"]
+                    action = key_map[np.random.choice(possible_actions)]
+                    fire_at_loc = sim.W.agents[0].fire_in_direction(action)
+                    if not fire_at_loc or count > 10:
+                        break
+                    count += 1
+                    avoided += 1
+            sprime, reward, done, _ = sim.step(action)
+            total_reward += reward
+        totals.append(total_reward)
+        deaths += len(sim.W.agents) == 0
+    totals = np.array(totals, dtype=np.float64)
+    # 400 episodes: a loose check of the level (std ~ 285 -> 4 s.e. ~ 57) - the tight one is the batched test above
+    assert abs(totals.mean() - REFERENCE_BASELINE_MEAN[size]) < 4 * totals.std() / np.sqrt(len(totals)) + 5
+    assert avoided > 50, "fire_in_direction never reported fire: the avoidance branch was not exercised"
+    assert 0 < deaths < 60
+    sim.close()
+
+
+def test_fire_in_direction_on_a_constructed_state(wf):
+    """Agent.fire_in_direction (environment.py:158-160): burning neighbour yes / no, and off-grid is False."""
+    sim = wf.ForestFire(size=10)
+    planes = np.zeros((1, 10, 10, 4), dtype=np.int8)
+    planes[..., 1] = 20
+    planes[0, 0, 4, 0], planes[0, 0, 4, 3] = 3, 1               # agent at x=4, y=0 (top row) on dirt
+    planes[0, 0, 5, 0], planes[0, 0, 5, 2] = 1, 25              # fire to the east (x=5, y=0)
+    planes[0, 1, 4, 0] = 2                                      # burnt cell to the south
+    sim._b.upload(planes)
+    sim.W._refresh()
+    ag = sim.W.agents[0]
+    assert (ag.x, ag.y) == (4, 0)
+    assert ag.fire_in_direction(2) and ag.fire_in_direction("E")
+    assert not ag.fire_in_direction(3) and not ag.fire_in_direction("S")
+    assert not ag.fire_in_direction(0)                           # off the grid
+    sim.close()
 
 
 # ---------------------------------------------------------------- consumers of the path

@@ -15,15 +15,19 @@ def test_oracle_reproduces_reference(path):
     ep = Episodes(path)
     planes = ep.init_planes.copy()
     envs = ep.init_envs.copy()
-    n_contained = 0
+    n_contained = n_burning_dirt = 0
+    op = O.default_params(allow_dig_toggle=int("toggle" in path))      # constants.py:46 as the generator set it
     for t in range(ep.T):
         actions, _ = ep.actions_at(t)
-        reward, done = O.step(planes, envs, actions)
+        reward, done = O.step(planes, envs, actions, op)
         obs = O.get_state(planes)
         live = ep.check_step(t, planes, envs, reward, done, obs)
         n_contained += int((reward[live] == 1000.0).sum())
+        n_burning_dirt += int((planes[live][..., 0] == 5).sum())
     if "circle" in path:
         assert n_contained > 0, "circle fixtures must exercise the containment reward"
+    if "toggle" in path:
+        assert n_burning_dirt > 20, "toggle fixtures must hold dirt cells that keep burning (dig on a burning cell)"
 
 
 def test_known_answer_noop_10():
@@ -74,3 +78,24 @@ def test_reset_default_law():
     O.reset(p2, e2, seed=7, env_id0=32)
     np.testing.assert_array_equal(p2, planes[32:])
     np.testing.assert_array_equal(e2, envs[32:])
+
+
+@pytest.mark.parametrize("size", [10, 14])
+def test_oracle_reproduces_the_published_baseline_reward(size):
+    """The reference publishes the mean episode reward of its clockwise random-walk baseline policy
+    (DQN.py:286-389): 1130.2 at 10x10 and 1151.4 at 14x14 over 10 x 10 000 episodes
+    (Plots/results_first.txt:2,20).  The oracle under the same policy (tests/policy_util.py), default
+    fuel 20, containment on, reset law of wfo_reset, must land on it within 4 standard errors."""
+    from tests.policy_util import (REFERENCE_BASELINE_MEAN, baseline_tolerance, run_baseline_episodes)
+    B = 40960
+    op = O.default_params(containment=1)
+    planes, envs = O.new_state(B, size, size)
+    rng = np.random.default_rng(size)
+    total, died, steps = run_baseline_episodes(
+        lambda: O.reset(planes, envs, seed=2024 + size, params=op),
+        lambda a: (lambda r, d: (r, d.astype(bool)))(*O.step(planes, envs, a, op)),
+        lambda: (envs["x"], envs["y"], (envs["flags"] & O.F_ALIVE) != 0, planes[..., 0] == 1),
+        B, rng)
+    tol = baseline_tolerance(total.std(), B)
+    assert abs(total.mean() - REFERENCE_BASELINE_MEAN[size]) < tol, (total.mean(), tol)
+    assert 0.01 < died.mean() < 0.15 and 60 < steps.mean() < 200

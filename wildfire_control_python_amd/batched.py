@@ -152,6 +152,12 @@ class BatchedForestFire:
         self._ck(self._lib.wf_download(self._h, N.ptr(planes), N.ptr(envs)), "wf_download")
         return planes, envs
 
+    def download_envs(self):
+        """Only the per-environment records (16 B each): agent position, flags, episode, tick."""
+        envs = np.empty(self.batch, dtype=N.ENV_DTYPE)
+        self._ck(self._lib.wf_download(self._h, None, N.ptr(envs)), "wf_download")
+        return envs
+
     def envs_from_planes(self, planes):
         envs = np.zeros(self.batch, dtype=N.ENV_DTYPE)
         ag = planes[..., N.P_AGENT] != 0

@@ -71,6 +71,11 @@ struct EnvKey {
 constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 | (2u | 1u << 2 | 16u) << 12 |
                               (0u | 1u << 2 | 16u) << 18 | (1u | 1u << 2) << 24;
 
+// cell types dig() turns into dirt on a MOVE (environment.py:151-152: not burning; :127: not dirt already):
+// grass, burnt, blocked burnt.  Bit t of the set = type t.  toggle_digging() digs under the agent without the
+// "not burning" guard: DIG_SET | fire.
+constexpr uint32_t DIG_SET = (1u << WF_GRASS) | (1u << WF_BURNT) | (1u << WF_BURNT_BLOCKED);
+
 typedef const WfCold __attribute__((address_space(4))) *cold_ptr;
 
 }  // namespace wfdev

@@ -166,6 +166,21 @@ __device__ __forceinline__ void flood(u64 (&R)[4], const u64 (&P)[4])
     }
 }
 
+// A burning cell that dig() retyped to dirt (WF_DIRT_BURNING, allow_dig_toggle only) is impassable, yet the
+// reference's search STARTS from it (the start node's own weight is never charged, pyastar/astar.cpp:41-116):
+// it reaches the border iff one of its 4-neighbours does.  Z = those cells; R = the flooded board.
+template <int W, int H>
+__device__ __forceinline__ void add_blocked_burning(u64 (&R)[4], const u64 (&Z)[4])
+{
+    u64 n[4];
+    static_for<4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        n[j] = (nb_up<W, H, j>(R) | nb_dn<W, H, j>(R) | nb_lf<W, H, j>(R) | nb_rt<W, H, j>(R)) & Z[j];
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) R[j] |= n[j];
+}
+
 // ----------------------------------------------------------------------------
 // fused observation: World.get_state() (environment.py:399-402) from registers
 // ----------------------------------------------------------------------------
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256) void wf_get_state_kernel(const uint32_t *__res
         int8_t *o = obs + i * 3;
         o[0] = (int8_t)(c >> 24);
         o[1] = (int8_t)(t == WF_FIRE);
-        o[2] = (int8_t)(t != WF_DIRT && t != WF_WATER);
+        o[2] = (int8_t)(t < WF_DIRT);                 // fire_mobility != inf
     }
 }
 

@@ -75,15 +75,17 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
     const uint32_t td = pe[(size_t)qd * 4], tcur = pe[(size_t)qa * 4];
     const uint32_t moved = inb & (td != WF_WATER ? 1u : 0u);                          // :146 traversable
     const uint32_t dfire = moved & (td == WF_FIRE ? 1u : 0u);
-    uint32_t dug = moved & ((fl >> 2) & 1u) & ((td == WF_GRASS || td == WF_BURNT) ? 1u : 0u);   // :151-152, :125-133
+    uint32_t dug = moved & ((fl >> 2) & 1u) & (DIG_SET >> td) & 1u;                   // :151-152, :125-133
+    uint32_t dugtype = WF_DIRT;
     const uint32_t vis_before = (fl >> 1) & 1u;
     fl = (fl & ~(ism << 1)) | (moved << 1) | (dfire << 3);                            // :142, :148-149, :154-155
     if (moved) { ax = nx; ay = ny; }
     uint32_t ta = moved ? td : tcur;
     if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && act == 4u) {                              // forest_fire.py:35-36
         fl ^= WF_F_DIGGING;
-        // divergence (documented): a burning cell is left burning (see wf_kernels.hip)
-        dug = ((fl >> 2) & 1u) & ((tcur == WF_GRASS || tcur == WF_BURNT) ? 1u : 0u);
+        // dig() under the agent: a BURNING cell too, which keeps burning under its new type (WF_DIRT_BURNING)
+        dug = ((fl >> 2) & 1u) & ((DIG_SET | 2u) >> tcur) & 1u;
+        if (tcur == WF_FIRE) dugtype = WF_DIRT_BURNING;
         qd = qa;
     }
     if (dug) ta = WF_DIRT;
@@ -100,24 +102,27 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
         if (dug && !flood) {
             const uint32_t xd = qd % W, yd = qd / W;
             uint32_t ring = 0, bn = 0;
+            bool zn = false;
             const int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
             for (int r = 0; r < 8; ++r) {
                 const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
                 if (rx < W && ry < H) {
-                    if (pe[(size_t)(ry * W + rx) * 4] < WF_DIRT) ring |= 1u << r;
+                    const uint32_t ty = pe[(size_t)(ry * W + rx) * 4];
+                    if (ty < WF_DIRT) ring |= 1u << r;
+                    if (ty == WF_DIRT_BURNING && !(r & 1)) zn = true;      // burning dirt hangs on the board through its neighbours
                     if (!(r & 1) && (rx == 0 || ry == 0 || rx == W - 1 || ry == H - 1)) bn |= 1u << r;
                 }
             }
             const uint32_t even = ring & 0x55u;
             const uint32_t eff = ring & 0xAAu & (even << 1) & ((even >> 1) | (even << 7));
             const bool onb = xd == 0 || yd == 0 || xd == W - 1 || yd == H - 1;
-            flood = (__popc(even) - __popc(eff) >= 2) || (onb && even && !(ring & bn));
+            flood = (__popc(even) - __popc(eff) >= 2) || (onb && even && !(ring & bn)) || zn;
         }
         if (flood) m |= MODE_FLOOD;
     }
     mode[e] = (uint8_t)m;
     if (vis_before) pe[(size_t)qa * 4 + 3] = 0;
-    if (dug) pe[(size_t)qd * 4] = (uint8_t)WF_DIRT;
+    if (dug) pe[(size_t)qd * 4] = (uint8_t)dugtype;
     if (fl & WF_F_VISIBLE) pe[(size_t)(ay * W + ax) * 4 + 3] = 1;
     ev.x = ax | (ay << 16);
     ev.y = fl;
@@ -163,7 +168,7 @@ __device__ __forceinline__ void still_masks(const uint4 &r, u64 (&S)[4])
     const uint32_t c[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
     for (int j = 0; j < 4; ++j)   // reduce_fuel (environment.py:297-307): fire cell with fuel-1 > 0
-        S[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);
+        S[j] = __ballot((c[j] & 3u) == 1u) & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);   // burning = fire or burning dirt
 }
 
 // The step runs IN PLACE (planes_out == planes).  The masks of the two rows just outside the workgroup - which
@@ -187,7 +192,7 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
         u64 anyign = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+            const u64 F = __ballot((c[j] & 3u) == 1u);
             // fuel -= 1 and fire -> burnt (+0xFFFFFF01) unless still burning (+0xFFFFFF00): the burn-out
             // lanes arrive as the carry-in of one add
             c[j] = addc(c[j], lanebit(F) ? 0xFFFFFF00u : 0u, F & ~Sc[j]);
@@ -212,7 +217,7 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+            FIRE[j] = __ballot((c[j] & 3u) == 1u);
             GR[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
         }
     }
@@ -420,7 +425,25 @@ __global__ __launch_bounds__(256) void wf_big_flood(const WfArgs a, const uint8_
         __syncthreads();
     }
     u64 *out = a.reach + (size_t)e * words;
-    for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = reach[k];
+    if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+        // Burning dirt (WF_DIRT_BURNING) is impassable, yet the reference's search starts FROM it: it reaches the
+        // border iff one of its 4-neighbours does.  One row per wave iteration: re-read the row, add those cells.
+        for (uint32_t r = wv; r < H; r += 4u) {
+            uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+            if (lane < LW) c = src[r * LW];
+            const u64 Z[4] = { __ballot((c.x & 0xffu) == WF_DIRT_BURNING), __ballot((c.y & 0xffu) == WF_DIRT_BURNING),
+                               __ballot((c.z & 0xffu) == WF_DIRT_BURNING), __ballot((c.w & 0xffu) == WF_DIRT_BURNING) };
+            if (lane < 4u) {
+                const uint32_t j = lane, k = r * 4u + j;
+                u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);
+                nb |= j > 0 ? reach[k - 1] : (reach[k + 3] << 1);
+                nb |= j < 3 ? reach[k + 1] : (reach[k - 3] >> 1);
+                out[k] = reach[k] | (nb & Z[j]);
+            }
+        }
+    } else {
+        for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = reach[k];
+    }
     // (never true with the H*W bound; kept so that a board that did not converge could not be trusted later)
     if (threadIdx.x == 0 && converged) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
 }
@@ -462,7 +485,16 @@ __global__ __launch_bounds__(256) void wf_cells_flood(const WfArgs a, const uint
         __syncthreads();
     }
     uint8_t *out = reinterpret_cast<uint8_t *>(a.reach) + (size_t)e * cells;
-    for (uint32_t q = threadIdx.x; q < cells; q += 256u) out[q] = board[q] >> 1;
+    for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
+        uint8_t v = board[q] >> 1;
+        if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (se[q] & 0xffu) == (uint32_t)WF_DIRT_BURNING) {
+            // burning dirt: impassable, but the reference's search starts from it -> reached iff a 4-neighbour is
+            const uint32_t x = q % W, y = q / W;
+            v = ((x > 0 && board[q - 1] == 3) || (x + 1 < W && board[q + 1] == 3) ||
+                 (y > 0 && board[q - W] == 3) || (y + 1 < H && board[q + W] == 3)) ? 1 : 0;
+        }
+        out[q] = v;
+    }
     if (threadIdx.x == 0) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
 }
 
@@ -479,9 +511,9 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
         uint32_t c = se[q];
         const uint32_t m = mode[e] & MODE_MASK;
         if (m == MODE_STEP && (a.update_mask & 1ull)) {
-            auto still = [&](uint32_t v) -> uint32_t { return ((v & 0xffu) == WF_FIRE && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
+            auto still = [&](uint32_t v) -> uint32_t { return ((v & 3u) == 1u && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
             const uint32_t t = c & 0xffu;
-            if (t == WF_FIRE) {
+            if ((t & 3u) == 1u) {                                                  // burning: fire or burning dirt
                 c = c + 0xFFFFFF01u - still(c);                                    // reduce_fuel :297-307
             } else if (t == WF_GRASS) {
                 uint32_t cnt = 0;                                                  // get_neighbours :311-326
@@ -499,18 +531,18 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
         if (m == MODE_STEP) {
             const uint32_t t = c & 0xffu;
             // containment (environment.py:345-377): a burning cell on a border-connected cell
-            if ((mode[e] & MODE_PRECHECK) && t == WF_FIRE && reinterpret_cast<const uint8_t *>(a.reach)[(size_t)e * cells + q])
+            if ((mode[e] & MODE_PRECHECK) && (t & 3u) == 1u && reinterpret_cast<const uint8_t *>(a.reach)[(size_t)e * cells + q])
                 atomicOr(&acc[2 * e], 4u);
             // wave-aggregated when the whole wave sits in one env (the common case)
             const uint32_t e0 = rfl(e);
             if (__ballot(e != e0) == 0) {
-                const u64 f = __ballot(t == WF_FIRE), g = __ballot(t == WF_GRASS);
+                const u64 f = __ballot((t & 3u) == 1u), g = __ballot(t == WF_GRASS);
                 if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) {
                     if (f) atomicOr(&acc[2 * e], 1u);
                     if (g) atomicAdd(&acc[2 * e + 1], (uint32_t)__popcll(g));
                 }
             } else {
-                if (t == WF_FIRE) atomicOr(&acc[2 * e], 1u);
+                if ((t & 3u) == 1u) atomicOr(&acc[2 * e], 1u);
                 if (t == WF_GRASS) atomicAdd(&acc[2 * e + 1], 1u);
             }
         }

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 const uint32_t tcur = type_of(tp, qa);
                 const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u);         // :146 traversable
                 const uint32_t dfire = moved & (2u >> td);                             // destination burning
-                uint32_t dug = moved & (fl >> 2) & (5u >> td) & 1u;                    // digging, grass|burnt (:151-152, :125-133)
+                uint32_t dug = moved & (fl >> 2) & (DIG_SET >> td) & 1u;               // digging, not burning, not dirt yet (:151-152, :125-133)
+                uint32_t dugtype = (uint32_t)WF_DIRT;
                 fl = (fl & ~(ism << 1)) | (moved << 1) | (dfire << 3);                 // :142, :148-149, :154-155
                 ax += moved * (nx - ax);
                 ay += moved * (ny - ay);
@@ -181,9 +182,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
                     if (rfl(act == 4u ? 1u : 0u)) {
                         fl ^= WF_F_DIGGING;
-                        // divergence (documented): the reference also retypes a BURNING cell to dirt
-                        // here while keeping it in burning_cells; this build leaves it burning.
-                        dug = (fl >> 2) & (5u >> tcur) & 1u;
+                        // dig() under the agent: a BURNING cell too, which stays in burning_cells under its
+                        // new type (WF_DIRT_BURNING)
+                        dug = (fl >> 2) & ((DIG_SET | 2u) >> tcur) & 1u;
+                        dugtype = tcur == (uint32_t)WF_FIRE ? (uint32_t)WF_DIRT_BURNING : dugtype;
                         qd = qa;
                     }
                 }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                     // per-lane selector: component to retype on the owning lane, >= 4 elsewhere
                     const uint32_t sel = (qd & 3u) + ((min((qd >> 2) ^ lane, 1u) | (dug ^ 1u)) << 2);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) t[j] = (sel == (uint32_t)j) ? (uint32_t)WF_DIRT : t[j];
+                    for (int j = 0; j < 4; ++j) t[j] = (sel == (uint32_t)j) ? dugtype : t[j];
                 }
 
                 // ---- ForestFire.update (forest_fire.py:85-106)
@@ -206,9 +208,9 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // reduce_fuel (:297-307): a fire cell whose fuel-1 > 0 keeps burning
-                        const uint32_t key = (t[j] << 8) + u[j];
-                        STILL[j] = __ballot((key - 0x102u) < 0x7Eu);                   // t==1 && 2<=fuel<=127
-                        const uint32_t isfire = (2u >> t[j]) & 1u;
+                        const uint32_t key = ((t[j] & 3u) << 8) + u[j];               // burning: fire (1) or burning dirt (5)
+                        STILL[j] = __ballot((key - 0x102u) < 0x7Eu);                   // burning && 2<=fuel<=127
+                        const uint32_t isfire = (0x22u >> t[j]) & 1u;
                         u[j] = (u[j] - isfire) & 0xffu;
                         t[j] += isfire;                                                // fire -> burnt ...
                     }
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 }
                 u64 FIRE[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot(t[j] == WF_FIRE);
+                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((t[j] & 3u) == 1u);
                 const uint32_t anyfire = (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;   // wave-uniform
                 if (do_update)
                     fl &= ~(((fl & anyfire) ^ 1u) << 4);                               // :105-106 (!alive || !fire) -> !RUNNING
@@ -272,6 +274,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
                         const uint32_t runs = (uint32_t)__popc(ring & ~rot);
                         recompute |= dug & (onb | (runs >> 1) | (runs >> 2));
+                        if (a.hot_flags & WF_HOT_DIG_TOGGLE)      // digging next to burning dirt may cut its last link (see wf_step_group)
+                            recompute |= dug & ((uint32_t)__ballot(ty == (uint32_t)WF_DIRT_BURNING && !rout && lane < 8u && !(lane & 1u)) ? 1u : 0u);
                     }
                     if (rfl(recompute)) {
                         u64 PASS[4];
@@ -279,6 +283,12 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         for (int j = 0; j < 4; ++j) PASS[j] = ~__ballot(t[j] >= WF_DIRT);
                         static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                         flood<W, H>(RB, PASS);
+                        if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                            u64 Z[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) Z[j] = __ballot(t[j] == (uint32_t)WF_DIRT_BURNING);
+                            add_blocked_burning<W, H>(RB, Z);
+                        }
                         fl = (fl | WF_F_REACH_VALID) & ~(uint32_t)WF_F_REACH_ROWS;      // the rows-layout board is stale now
                         if (lane == 0) {
                             ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(a.reach + (size_t)e * 4);

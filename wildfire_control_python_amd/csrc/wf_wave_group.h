@@ -60,7 +60,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
     const uint32_t xd = istog ? ax : (inb ? nx : ax), yd = istog ? ay : (inb ? ny : ay);
     // Containment shortcut: gather the passability of the 8-ring (N,NE,E,SE,S,SW,W,NW) around
     // the cell that may get dug; off-grid = impassable.
-    uint32_t ring = 0, bnmask = 0;
+    uint32_t ring = 0, bnmask = 0, zring = 0;        // zring: ring cells that are burning dirt (toggle only)
     const uint32_t precheck0 = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
     if (__ballot(precheck0 & running) != 0) {        // wave-uniform: nobody needs the test otherwise
         const uint32_t qx = istog ? qa : qd;
@@ -74,6 +74,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
             const uint32_t nq = off ? 0u : qx + (uint32_t)(DY[r] * W + DX[r]);
             const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
             ring |= ((off ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
+            if (toggling) zring |= ((off ^ 1u) & (ty == (uint32_t)WF_DIRT_BURNING ? 1u : 0u)) << r;
         }
         // which 4-neighbours (ring bits 0,2,4,6 = N,E,S,W) are border cells themselves
         const uint32_t ex = x0 | xl, ey = y0 | yl;
@@ -82,7 +83,8 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
     }
     const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u) & running;           // :146 traversable
     const uint32_t dfire = moved & (2u >> td);                                         // destination burning
-    uint32_t dug = moved & (fl >> 2) & (5u >> td) & 1u;                                // :151-152, :125-133
+    uint32_t dug = moved & (fl >> 2) & (DIG_SET >> td) & 1u;                           // :151-152, :125-133 (not dirt, not burning)
+    uint32_t dugtype = (uint32_t)WF_DIRT;
     const uint32_t vis_before = (fl >> 1) & 1u & running;
     fl = (fl & ~((ism & running) << 1)) | (moved << 1) | (dfire << 3);                 // :142, :148-149, :154-155
     ax += moved * (nx - ax);
@@ -91,11 +93,12 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
     {   // Agent.toggle_digging (forest_fire.py:35-36, environment.py:136-138)
         const uint32_t tg = istog & running;
         fl ^= tg << 2;
-        // divergence (documented): the reference also retypes a BURNING cell to dirt here
-        // while keeping it in burning_cells; this build leaves it burning.
-        const uint32_t dugt = (fl >> 2) & (5u >> tcur) & 1u;
+        // dig() under the agent: any cell that is not dirt - a BURNING one too, which stays in burning_cells
+        // under its new type (WF_DIRT_BURNING)
+        const uint32_t dugt = (fl >> 2) & ((DIG_SET | 2u) >> tcur) & 1u;
         dug = tg ? dugt : dug;
         qd = tg ? qa : qd;
+        dugtype = (tg & (2u >> tcur) & 1u) ? (uint32_t)WF_DIRT_BURNING : dugtype;
     }
     ta += dug * ((uint32_t)WF_DIRT - ta);
     if (do_update) {   // forest_fire.py:87 drop dead agents (Agent.is_dead environment.py:116-120)
@@ -106,7 +109,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
     const uint32_t qa_new = ay * W + ax;
     // apply the touched bytes to the grid in memory (phase B reloads the whole grid)
     if (vis_before) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qa * 4u + 3u)) = 0;
-    if (dug) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qd * 4u)) = (uint8_t)WF_DIRT;
+    if (dug) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qd * 4u)) = (uint8_t)dugtype;
     if (vis_after & running) *reinterpret_cast<uint8_t *>(planes_b + (pbase + qa_new * 4u + 3u)) = 1;
     // Verdict: can this dig change which cells reach the border?  Digging cell X re-routes
     // nothing iff the passable 4-neighbours of X stay connected to each other around the ring
@@ -122,7 +125,9 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
         const uint32_t comps = (uint32_t)__popc(even) - (uint32_t)__popc(eff);
         const uint32_t local_fail = (comps + 0x7FFFFFFEu) >> 31;              // comps >= 2 (comps in 0..4)
         const uint32_t border_fail = onb & min(even, 1u) & (min(ring & bnmask, 1u) ^ 1u);
-        ringflag = dug & (local_fail | border_fail) & 1u;
+        // a burning-dirt 4-neighbour hangs on the board through its neighbours only (add_blocked_burning): digging
+        // next to it may have been its last link, which the passable-cell argument above does not see
+        ringflag = dug & (local_fail | border_fail | min(zring & 0x55u, 1u)) & 1u;
     }
     const uint32_t precheck = ((a.hot_flags & WF_HOT_CONTAINMENT) ? 1u : 0u) & (((fl >> 5) | (fl >> 6)) ^ 1u) & 1u;
     const uint32_t Pv = running | (precheck << 1) | (((fl >> VB) & 1u) << 2) | (ringflag << 3);   // VB: this layout's board-valid flag
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // reduce_fuel (environment.py:297-307)
-                    const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+                    const u64 F = __ballot((c[j] & 3u) == 1u);                         // burning: fire or burning dirt
                     STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                     // fuel -= 1 and fire -> burnt, unless still burning (type stays fire)
                     const uint32_t d = lanebit(STILL[j]) ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                 R |= __ballot((ign_bits & bgeo) != 0u) ? RB_BORDER : 0u;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE);
+                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((c[j] & 3u) == 1u);
             }
             const bool anyfire = (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) != 0;
             R |= anyfire ? RB_ANYFIRE : 0u;
@@ -354,6 +359,12 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     for (int j = 0; j < 4; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
                     static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                     flood<W, H>(RB, PASS);
+                    if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                        u64 Z[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Z[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_DIRT_BURNING);
+                        add_blocked_burning<W, H>(RB, Z);
+                    }
                     if (lane == 0) {
                         ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(a.reach + (size_t)e * 4);
                         rp[0] = make_ulonglong2(RB[0], RB[1]);

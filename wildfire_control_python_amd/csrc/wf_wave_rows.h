@@ -354,7 +354,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
                         // reduce_fuel (environment.py:297-307); finished environments hold no "fire" here
-                        const u64 F = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & RUNM;
+                        const u64 F = __ballot((c[j] & 3u) == 1u) & RUNM;               // burning: fire or burning dirt
                         STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                         const bool st = lanebit(STILL[j]);
                         sv[j] = st ? 1u : 0u;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
                 } else {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
-                        const u64 FJ = __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & RUNM;
+                        const u64 FJ = __ballot((c[j] & 3u) == 1u) & RUNM;
                         FIREALL |= FJ;
                         HITS |= FJ & RBG[j];
                     }
@@ -406,11 +406,23 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
                     for (int j = 0; j < CPL; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
                     static_for<CPL>([&](auto J) { constexpr int j = decltype(J)::value; NB[j] = R::template BORDER<j> & PASS[j]; });
                     flood_rows<W, H, S>(NB, PASS);
+                    if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                        // burning dirt reaches the border through its 4-neighbours (see add_blocked_burning)
+                        u64 ZB[CPL], ADD[CPL];
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) ZB[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_DIRT_BURNING);
+                        static_for<CPL>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            ADD[j] = ((NB[j] << S) | (NB[j] >> S) | rg_lf<W, H, S, j>(NB) | rg_rt<W, H, S, j>(NB)) & ZB[j];
+                        });
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) NB[j] |= ADD[j];
+                    }
                     HITS = 0;
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
                         RBG[j] = (RBG[j] & ~NEEDM) | (NB[j] & NEEDM);
-                        HITS |= __ballot((c[j] & 0xffu) == (uint32_t)WF_FIRE) & RUNM & RBG[j];
+                        HITS |= __ballot((c[j] & 3u) == 1u) & RUNM & RBG[j];
                     }
                     rb_dirty = true;
                 }

@@ -13,14 +13,19 @@ DQN.py / DQN_SARSA.py style loops run against it unchanged.  reset() draws the
 spawn point from numpy's legacy global stream in the reference's own order, so
 `np.random.seed(s); sim.reset()` spawns the agent exactly where the reference does.
 """
+import pprint
 from collections import deque
 
 import numpy as np
 
 from . import _native as N
 from .batched import BatchedForestFire, encode_action
-from .utility import (color2ascii, get_name, grass, layer, temp_from_count, type2ascii,
-                      type2gray, types)
+from .utility import get_name, grass, layer, temp_from_count, type2ascii, type2gray
+
+# look-up tables indexed by the boundary's type code (0..6; 5 = burning dirt, 6 = blocked burnt: include/wildfire.h)
+_REF_TYPE = np.array([0, 1, 2, 3, 4, 3, 2], dtype=np.int64)    # the type the reference's World.env would hold
+_ASCII = np.array([type2ascii[int(t)] for t in _REF_TYPE])
+_GRAY = np.array([type2gray[int(t)] for t in _REF_TYPE])
 
 
 class Agent:
@@ -76,7 +81,7 @@ class World:
             self.agents = [Agent(self, self._env["x"], self._env["y"], fl & N.F_DIGGING, fl & N.F_DEAD)]
         else:
             self.agents = []
-        ys, xs = np.nonzero(self._planes[:, :, N.P_TYPE] == N.FIRE)
+        ys, xs = np.nonzero((self._planes[:, :, N.P_TYPE] & 3) == 1)      # fire, or dirt dug under a fire (code 5)
         self.burning_cells = set(zip(xs.tolist(), ys.tolist()))
         # the reference's deque shrinks while it searches; only "empty <=> containment
         # already paid" is observable to callers (environment.py:345, misc.py:39)
@@ -84,14 +89,13 @@ class World:
         if not (fl & N.F_CONTAINED):
             self.reset_border_points()
 
-    def reset_border_points(self):                              # environment.py:215-222
-        self.border_points = deque()
-        for x in range(self.WIDTH):
-            self.border_points.append([x, 0])
-            self.border_points.append([x, self.HEIGHT - 1])
-        for y in range(self.HEIGHT):
-            self.border_points.append([0, y])
-            self.border_points.append([self.HEIGHT - 1, y])
+    def reset_border_points(self):
+        """All border coordinates ([x, y] pairs, corners twice like the reference's deque, environment.py:215-222).
+        Only its emptiness is ever observed from outside (misc.py:39)."""
+        xs, ys = np.arange(self.WIDTH), np.arange(self.HEIGHT)
+        top_bottom = np.stack([np.repeat(xs, 2), np.tile([0, self.HEIGHT - 1], self.WIDTH)], axis=1)
+        left_right = np.stack([np.tile([0, self.HEIGHT - 1], self.HEIGHT), np.repeat(ys, 2)], axis=1)   # (sic) HEIGHT-1 as an x
+        self.border_points = deque(np.concatenate([top_bottom, left_right]).tolist())
 
     def reset(self):
         self._sim.reset()
@@ -101,18 +105,19 @@ class World:
         """float64 (W, H, 9) array laid out like the reference's World.env
         (environment.py:38-50), rebuilt from the int8 planes; read-only view."""
         p = self._planes
-        t = p[:, :, N.P_TYPE].T.astype(np.float64)
+        code = p[:, :, N.P_TYPE].T
+        t = _REF_TYPE[code].astype(np.float64)                  # codes 5 / 6 read dirt / burnt in the reference
         out = np.zeros((self.WIDTH, self.HEIGHT, 9))
         out[:, :, layer["type"]] = t
-        out[:, :, layer["gray"]] = np.vectorize(type2gray.get)(p[:, :, N.P_TYPE].T)
+        out[:, :, layer["gray"]] = _GRAY[code]
         out[:, :, layer["temp"]] = np.vectorize(lambda n: temp_from_count(n, self.wind_speed))(
             p[:, :, N.P_HEAT].T)
         out[:, :, layer["heat"]] = grass["heat"]
         out[:, :, layer["fuel"]] = p[:, :, N.P_FUEL].T
         out[:, :, layer["threshold"]] = grass["threshold"]
         out[:, :, layer["agent_pos"]] = p[:, :, N.P_AGENT].T
-        out[:, :, layer["fire_mobility"]] = np.where(t >= N.DIRT, np.inf, 1.0)
-        out[:, :, layer["agent_mobility"]] = np.where(t == N.WATER, np.inf, 1.0)
+        out[:, :, layer["fire_mobility"]] = np.where(code >= N.DIRT, np.inf, 1.0)
+        out[:, :, layer["agent_mobility"]] = np.where(code == N.WATER, np.inf, 1.0)
         out.setflags(write=False)
         return out
 
@@ -140,56 +145,44 @@ class World:
         its border deque, environment.py:342-390; here the step kernel produced it)."""
         return self._last_reward
 
-    def print_state(self, state):                               # environment.py:405-420
-        for y in range(state.shape[1]):
-            for x in range(state.shape[1]):
-                if state[0, x, y, 0]:
-                    print("A", end="")
-                elif state[0, x, y, 1]:
-                    print("@", end="")
-                elif not state[0, x, y, 2]:
-                    print("0", end="")
-                else:
-                    print("+", end="")
-            print("")
-        print("")
+    # ---- debug printers of misc.run_human (misc.py:61-72): same text as the reference prints, built from the
+    # int8 planes with table look-ups instead of per-cell Python branches
+    def print_state(self, state):                               # what the learner sees (environment.py:405-420)
+        st = np.asarray(state)[0]                               # [x, y, k]
+        sym = np.where(st[..., 0] != 0, "A", np.where(st[..., 1] != 0, "@", np.where(st[..., 2] == 0, "0", "+")))
+        print("\n".join("".join(row) for row in sym.T) + "\n\n", end="")
 
-    def inspect(self, cell):                                    # environment.py:423-436
+    def inspect(self, cell):                                    # one cell (environment.py:423-436)
         x, y = cell
-        info = self.env[x, y, :]
-        gray = info[layer["gray"]]
-        print("\n[Color] Grayscale:", gray, "Ascii:", color2ascii[gray])
-        print("[Temperature] ", info[layer["temp"]])
-        print("[Heat Power] ", info[layer["heat"]])
-        print("[Fuel Level] ", info[layer["fuel"]])
-        print("[Ignition Threshold], ", info[layer["threshold"]])
-        here = bool(self.agents) and (self.agents[0].x, self.agents[0].y) == (x, y)
-        print("[Cell contains an Agent] ", here, "\n")
+        code, fuel, heat, _ = (int(v) for v in self._planes[y, x])
+        here = any((a.x, a.y) == (x, y) for a in self.agents[:1])
+        lines = [("\n[Color] Grayscale:", _GRAY[code], "Ascii:", _ASCII[code]),
+                 ("[Temperature] ", temp_from_count(heat, self.wind_speed)),
+                 ("[Heat Power] ", grass["heat"]),
+                 ("[Fuel Level] ", float(fuel)),
+                 ("[Ignition Threshold], ", float(grass["threshold"])),
+                 ("[Cell contains an Agent] ", here, "\n")]
+        for ln in lines:
+            print(*ln)
 
-    def print_info(self, total_reward):                         # environment.py:439-453
-        t = self._planes[:, :, N.P_TYPE]
-        n = self.WIDTH * self.HEIGHT
-        burnt, burning = int((t == N.BURNT).sum()), int((t == N.FIRE).sum())
-        dug, healthy = int((t == N.DIRT).sum()), int((t == N.GRASS).sum())
-        print("[# of Burnt Cells] ", burnt)
-        print("[# of Burning Cells] ", burning)
-        print("[# of Dug Cells] ", dug)
-        print("[# of Healthy Cells] ", healthy)
-        print("[# of Damaged Cells] ", dug + burnt + burning)
-        print("[Percent Burnt] ", burnt / n)
-        print("[Percent Damaged] ", (burnt + dug + burning) / n)
-        print("[Total Reward] ", total_reward)
+    def print_info(self, total_reward):                         # counts per cell type (environment.py:439-453)
+        n_of = np.bincount(_REF_TYPE[self._planes[:, :, N.P_TYPE]].ravel(), minlength=5)
+        cells = self.WIDTH * self.HEIGHT
+        burnt, burning, dug, healthy = (int(n_of[k]) for k in (N.BURNT, N.FIRE, N.DIRT, N.GRASS))
+        for label, value in (("[# of Burnt Cells] ", burnt), ("[# of Burning Cells] ", burning),
+                             ("[# of Dug Cells] ", dug), ("[# of Healthy Cells] ", healthy),
+                             ("[# of Damaged Cells] ", dug + burnt + burning), ("[Percent Burnt] ", burnt / cells),
+                             ("[Percent Damaged] ", (burnt + dug + burning) / cells), ("[Total Reward] ", total_reward)):
+            print(label, value)
         print("[Current Reward] ", self.get_reward(), "\n")
 
     def print_metadata(self):                                   # environment.py:456-460
-        import pprint
-        pprint.PrettyPrinter().pprint(self._sim.METADATA)
+        pprint.pprint(self._sim.METADATA)
         print("")
 
     def show_layer(self, layer_num=None):                       # environment.py:463-470
         if layer_num is None:
-            import pprint
-            pprint.PrettyPrinter().pprint(layer)
+            pprint.pprint(layer)
             print("")
         else:
             print(self.env[:, :, layer[layer_num]].T)
@@ -227,25 +220,16 @@ class ForestFire:
         return self.W.get_state()
 
     def render(self):                                           # forest_fire.py:57-82
-        print(" ", end="")
-        for x in range(self.width):
-            print(x % 10, end="")
+        """Prints the ascii map with index markers and returns it as one string (DQN.py:130,245 store it)."""
+        sym = _ASCII[self.W._planes[:, :, N.P_TYPE]]            # [y, x]
+        for a in self.W.agents[:1]:
+            sym[a.y, a.x] = "A"
+        rows = ["".join(r) for r in sym]
+        print(" " + "".join(str(x % 10) for x in range(self.width)))
+        for y, r in enumerate(rows):
+            print(f"{y % 10}{r}")
         print("")
-        return_map = "\n"
-        t = self.W._planes[:, :, N.P_TYPE]
-        for y in range(self.height):
-            print(y % 10, end="")
-            for x in range(self.width):
-                if self.W.agents and (self.W.agents[0].x, self.W.agents[0].y) == (x, y):
-                    symbol = "A"
-                else:
-                    symbol = type2ascii[int(t[y, x])]
-                return_map += symbol
-                print(symbol, end="")
-            return_map += "\n"
-            print("")
-        print("")
-        return return_map
+        return "\n" + "".join(r + "\n" for r in rows)
 
     def close(self):
         self._b.close()
