@@ -95,7 +95,8 @@ typedef struct wf_params {
     /* synthetic reset law for wf_reset / auto_reset (reference default: 20, 20, 0) */
     int32_t  fuel_lo, fuel_hi; /* fuel ~ U{lo..hi} per cell                            */
     uint32_t ignite_ppm;       /* extra pre-ignited grass cells per million             */
-    int32_t  reserved;
+    int32_t  make_rivers;      /* constants.py:44: reset draws the river of reset_map (environment.py:69-95) from the
+                                * counter-based stream (same law; a river through the fire cell is redrawn)  */
     uint64_t seed;             /* stream seed for auto_reset                            */
     uint64_t env_id0;          /* global id of env 0 of this context (multi-GPU shards) */
 } wf_params;

@@ -28,7 +28,7 @@ class Params(ctypes.Structure):
                 ("contained_bonus", ctypes.c_double), ("default_reward", ctypes.c_double),
                 ("allow_dig_toggle", ctypes.c_int32), ("containment", ctypes.c_int32),
                 ("fuel_lo", ctypes.c_int32), ("fuel_hi", ctypes.c_int32),
-                ("ignite_ppm", ctypes.c_uint32), ("reserved", ctypes.c_int32)]
+                ("ignite_ppm", ctypes.c_uint32), ("make_rivers", ctypes.c_int32)]
 
 
 def build(force=False):
@@ -65,6 +65,9 @@ def lib():
         L.wfo_circle_points.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                         ctypes.POINTER(ctypes.c_int)]
         L.wfo_circle_points.restype = ctypes.c_int
+        L.wfo_river.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")]
+        L.wfo_river.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -126,6 +129,13 @@ def circle_points(r):
     dy = (ctypes.c_int * 32)()
     n = lib().wfo_circle_points(int(r), dx, dy)
     return [(dx[i], dy[i]) for i in range(n)]
+
+
+def river(H, W, seed, env_id=0, episode=0):
+    """uint8 (H, W) water mask of the river wfo_reset would draw for (seed, env_id, episode)."""
+    water = np.zeros((H, W), dtype=np.uint8)
+    lib().wfo_river(int(H), int(W), int(seed), int(env_id), int(episode), water)
+    return water
 
 
 def new_state(batch, H, W):

@@ -75,6 +75,55 @@ static uint32_t below(uint32_t r, uint32_t n)
     return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32);
 }
 
+/* ------------------------------------------------------------------ river */
+
+/* reset_map's river (environment.py:69-95), one attempt: returns 1 if the river stays off the fire cell.
+ * Draws come from the river domain of the env's stream: index 0x80000000 + attempt * 0x10000 + n. */
+static int river_attempt(int H, int W, uint64_t seed, uint64_t id, uint32_t ep, uint32_t attempt, int keep_centre,
+                         uint8_t *water)
+{
+    uint32_t n = 0x80000000u + attempt * 0x10000u;
+    int fx = W / 2, fy = H / 2, crossed = 0;              /* utility.py:61-64 */
+    int x, y;
+#define D() wfo_rng_u32(seed, id, ep, n++)
+    memset(water, 0, (size_t)H * (size_t)W);
+    x = (int)below(D(), (uint32_t)W);                        /* :75 np.random.choice(range(WIDTH)) */
+    y = 1 + (int)below(D(), 3);                              /* :77 np.random.choice(d) */
+    while (y < H - (1 + (int)below(D(), 3))) {               /* :79 */
+        int nx = x, ny = y + 1, tries = 0, ok = 0;
+        if (x == fx && y == fy) {
+            crossed = 1;
+            if (!keep_centre) water[y * W + x] = 1;
+        } else {
+            water[y * W + x] = 1;                            /* :81-87 */
+        }
+        do {                                                 /* :89-93 */
+            int s = (D() & 1u) ? 1 : -1;                     /* np.random.choice([1, -1]) */
+            int a = 1 + (int)below(D(), 3), b = 1 + (int)below(D(), 3);
+            nx = x + s;
+            ok = (a <= nx && nx < W - b) || (nx == fx && ny == fy);
+        } while (!ok && ++tries < 64);
+        if (!ok)                                             /* never in practice: (2/3)^64 */
+            nx = x + 1 <= W - 2 ? x + 1 : x - 1;
+        x = nx;
+        y = ny;
+    }
+#undef D
+    return !crossed;
+}
+
+int wfo_river(int H, int W, uint64_t seed, uint64_t env_id, uint32_t episode, uint8_t *water)
+{
+    uint32_t attempt;
+    int i, n = 0;
+    for (attempt = 0; attempt < 8; ++attempt)
+        if (river_attempt(H, W, seed, env_id, episode, attempt, attempt == 7, water))
+            break;
+    for (i = 0; i < H * W; ++i)
+        n += water[i];
+    return n;
+}
+
 /* ---------------------------------------------------------- circle_points */
 
 /* utility.py:8-52, midpoint circle around (0,0), points in generation order */
@@ -495,6 +544,14 @@ int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
             else
                 w.fuel[i] = p->fuel_lo + (int)below(wfo_rng_u32(seed, id, ep, 16u + (uint32_t)i),
                                                     (uint32_t)(p->fuel_hi - p->fuel_lo + 1));
+        }
+        if (p->make_rivers) {                                /* :69-95 */
+            wfo_river(H, W, seed, id, ep, w.seen);
+            for (i = 0; i < n; ++i)
+                if (w.seen[i]) {
+                    w.type[i] = WFO_WATER;
+                    w.fmob_inf[i] = 1;
+                }
         }
         w.n_burning = 0;                                     /* :202 */
         w.fire_at_border = 0;

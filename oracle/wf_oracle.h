@@ -75,7 +75,7 @@ typedef struct {
     /* synthetic reset law (build extension; reference default = lo==hi==20, ppm 0) */
     int32_t fuel_lo, fuel_hi;
     uint32_t ignite_ppm;     /* extra pre-ignited grass cells per million  */
-    int32_t reserved;
+    int32_t make_rivers;     /* constants.py:44: reset_map draws a river (environment.py:69-95) */
 } wfo_params;
 
 #define WFO_HEAT_FORCED 25
@@ -101,6 +101,13 @@ int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
 
 /* World.get_state() (environment.py:399-402): int8 (batch, W, H, 3) indexed [b][x][y][k]. */
 int wfo_get_state(int batch, int H, int W, const int8_t *planes, int8_t *obs);
+
+/* The river of reset_map (environment.py:69-95) under the counter-based stream: water[y*W + x] = 1 on river cells.
+ * Same law as the reference's generator - start column uniform, start row in {1,2,3}, one cell per row, the column
+ * drifting by +-1 under the reference's acceptance test, the walk ending H - {1,2,3} rows down - conditioned on the
+ * river not crossing the fire cell (the reference would hold a burning cell with infinite fire mobility there, which
+ * the boundary format cannot express: such rivers are redrawn).  Returns the number of water cells. */
+int wfo_river(int H, int W, uint64_t seed, uint64_t env_id, uint32_t episode, uint8_t *water);
 
 /* The counter-based stream itself (for tests of the generator). */
 uint32_t wfo_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t draw);

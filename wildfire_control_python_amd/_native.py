@@ -33,7 +33,7 @@ class Params(ctypes.Structure):
                 ("death_penalty", ctypes.c_double), ("contained_bonus", ctypes.c_double),
                 ("default_reward", ctypes.c_double),
                 ("fuel_lo", ctypes.c_int32), ("fuel_hi", ctypes.c_int32),
-                ("ignite_ppm", ctypes.c_uint32), ("reserved", ctypes.c_int32),
+                ("ignite_ppm", ctypes.c_uint32), ("make_rivers", ctypes.c_int32),
                 ("seed", ctypes.c_uint64), ("env_id0", ctypes.c_uint64)]
 
 

@@ -74,6 +74,7 @@ class BatchedForestFire:
         lo, hi = fuel_range if fuel_range is not None else (grass["fuel"], grass["fuel"])
         p.fuel_lo, p.fuel_hi = int(lo), int(hi)
         p.ignite_ppm = int(ignite_ppm)
+        p.make_rivers = int(bool(self.METADATA["make_rivers"]))            # constants.py:44
         p.seed = self.seed
         p.env_id0 = int(env_id0)
         self.params = p
@@ -173,8 +174,6 @@ class BatchedForestFire:
     def reset(self, mask=None, seed=None):
         """World.reset() (environment.py:186-212) on the device for every env (or the
         masked ones), spawn points from the counter-based stream.  Returns the state."""
-        if self.METADATA["make_rivers"]:
-            raise NotImplementedError("make_rivers is only built for reset_host() (numpy stream, as the reference)")
         if seed is None:
             seed = self.seed + 0x9E3779B9 * self._reset_count
         self._reset_count += 1

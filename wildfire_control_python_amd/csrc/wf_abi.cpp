@@ -97,6 +97,13 @@ bool params_ok(const wf_params *p)
     return true;
 }
 
+// reset_map's river needs room for its margins (the reference asserts grids of at least 10x10, utility.py:68) and, in
+// the big-grid families, a row table in LDS
+bool rivers_ok(WfFamily fam, int H, int W)
+{
+    return H >= 8 && W >= 8 && (fam == WF_FAM_WAVE || H <= WF_RIVER_MAX_H);
+}
+
 WfArgs base_args(const wf_ctx *c)
 {
     WfArgs a;
@@ -115,7 +122,7 @@ WfArgs base_args(const wf_ctx *c)
     a.update_mask = ~0ull;
     a.ignite_count = c->p.ignite_count;
     a.hot_flags = (c->p.containment ? WF_HOT_CONTAINMENT : 0) | (c->p.auto_reset ? WF_HOT_AUTO_RESET : 0) |
-                  (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0);
+                  (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0) | (c->p.make_rivers ? WF_HOT_RIVERS : 0);
     a.group = c->knobs.group;          // experiment knob: cap on environments per wave of the single-step kernel
     a.default_reward = c->p.default_reward;
     a.death_penalty = c->p.death_penalty;
@@ -251,6 +258,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (fam == WF_FAM_CELLS && pp.containment && (long long)H * W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;   // byte board in LDS
     if (fam == WF_FAM_TILED && pp.containment && H > 1024) return WF_ERR_UNSUPPORTED;   // boards live in LDS (64 KiB)
     if (fam != WF_FAM_WAVE && (unsigned long long)H * W > 0xFFFFull * 0xFFFFull) return WF_ERR_UNSUPPORTED;
+    if (pp.make_rivers && !rivers_ok(fam, H, W)) return WF_ERR_UNSUPPORTED;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return WF_ERR_NO_DEVICE;
@@ -352,6 +360,7 @@ int wf_set_params(wf_ctx *c, const wf_params *p)
     if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
     if (c->fam == WF_FAM_CELLS && p->containment && (long long)c->H * c->W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
+    if (p->make_rivers && !rivers_ok(c->fam, c->H, c->W)) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));

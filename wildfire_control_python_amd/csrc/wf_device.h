@@ -66,6 +66,49 @@ struct EnvKey {
     __device__ __forceinline__ uint32_t draw(uint32_t d) const { return hash32(k0 ^ hash32(d + k1)); }
 };
 
+// ----------------------------------------------------------------------------
+// river of reset_map (environment.py:69-95) under the counter-based stream
+// ----------------------------------------------------------------------------
+// Same law as oracle/wf_oracle.c wfo_river (written independently): start column uniform, start row in {1,2,3}, one
+// water cell per row, the column drifting by +-1 under the reference's acceptance test, the walk ending H - {1,2,3}
+// rows down; a river through the fire cell is redrawn (up to 7 times; the 8th is taken minus that cell).  Every lane
+// of a wave holds the same key, so the walk is wave-uniform control flow.  mark(x, y) is called for every water cell.
+template <class F>
+__device__ __forceinline__ bool river_attempt(const EnvKey &key, int W, int H, uint32_t attempt, F &&mark)
+{
+    uint32_t n = 0x80000000u + attempt * 0x10000u;
+    const int fx = W / 2, fy = H / 2;                        // utility.py:61-64
+    bool crossed = false;
+    int x = (int)below(key.draw(n++), (uint32_t)W);          // :75
+    int y = 1 + (int)below(key.draw(n++), 3u);               // :77
+    while (y < H - (1 + (int)below(key.draw(n++), 3u))) {    // :79
+        if (x == fx && y == fy) crossed = true;
+        else mark(x, y);                                     // :81-87
+        const int ny = y + 1;
+        int nx = x, tries = 0;
+        bool ok = false;
+        do {                                                 // :89-93
+            const int s = (key.draw(n++) & 1u) ? 1 : -1;
+            const int a = 1 + (int)below(key.draw(n++), 3u), b = 1 + (int)below(key.draw(n++), 3u);
+            nx = x + s;
+            ok = (a <= nx && nx < W - b) || (nx == fx && ny == fy);
+        } while (!ok && ++tries < 64);
+        if (!ok) nx = x + 1 <= W - 2 ? x + 1 : x - 1;        // never in practice: (2/3)^64
+        x = nx;
+        y = ny;
+    }
+    return !crossed;
+}
+
+template <class F>
+__device__ __forceinline__ void river_cells(const EnvKey &key, int W, int H, F &&mark)
+{
+    uint32_t attempt = 0;
+    for (; attempt < 7u; ++attempt)
+        if (river_attempt(key, W, H, attempt, [](int, int) {})) break;
+    river_attempt(key, W, H, attempt, mark);
+}
+
 // move table, 6 bits per action 0..4: (dx+1) | (dy+1)<<2 | is_move<<4; entry 4 = "no move"
 // (N=(0,-1) S=(0,+1) E=(+1,0) W=(-1,0): environment.py:163-171)
 constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 | (2u | 1u << 2 | 16u) << 12 |
@@ -75,6 +118,16 @@ constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 |
 // grass, burnt, blocked burnt.  Bit t of the set = type t.  toggle_digging() digs under the agent without the
 // "not burning" guard: DIG_SET | fire.
 constexpr uint32_t DIG_SET = (1u << WF_GRASS) | (1u << WF_BURNT) | (1u << WF_BURNT_BLOCKED);
+
+// "burning" test on a packed cell word.  With the dig toggle a burning cell is WF_FIRE or WF_DIRT_BURNING: (type & 3) == 1.
+// Without it (RARE = false) those codes cannot arise and the plain byte compare is one instruction (SDWA) and no
+// temporary register.
+template <bool RARE>
+__device__ __forceinline__ bool burning(uint32_t c)
+{
+    if constexpr (RARE) return (c & 3u) == 1u;
+    else return (c & 0xffu) == (uint32_t)WF_FIRE;
+}
 
 typedef const WfCold __attribute__((address_space(4))) *cold_ptr;
 

@@ -25,7 +25,11 @@ struct WfCold {
     WfSpawn spawn;
 };
 
-enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4 };
+enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8 };
+// The two options that are off in the reference's default configuration (constants.py:44,46) live in separate
+// instantiations of the step kernels (template parameter RARE), so that they cost the default path neither
+// registers nor instructions.
+#define WF_HOT_RARE (WF_HOT_DIG_TOGGLE | WF_HOT_RIVERS)
 
 // Everything a step / reset launch needs on its hot path, passed by value (kernarg segment).
 struct WfArgs {
@@ -99,6 +103,7 @@ hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num
 // big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out
 // halo != nullptr (tiled family): the step runs IN PLACE (planes_out == planes); halo = u64[batch][gx][8] scratch
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s);
+#define WF_RIVER_MAX_H 2048       // big-grid families: rows of a grid whose river fits the reset kernel's LDS row table
 #define WF_CELLS_FLOOD_MAX 60000   // generic family: cells of a grid whose reachability byte board fits the flood kernel's LDS
 int wf_tiled_groups(int H);      // workgroups of wf_step_tiled per environment
 // sel == nullptr: all envs; sel_value >= 0: envs with sel[e] == sel_value; sel_value < 0: envs with sel[e] != 0

@@ -95,7 +95,7 @@ struct EnvS {        // wave-uniform scalars of one environment
 // World.reset() into registers (environment.py:186-212, reset_map :59-67,
 // get_agent_location utility.py:66-78) with the counter-based stream.
 // t/u/h: type, fuel (unsigned byte), heat quanta of the lane's 4 cells.
-template <int W, int H>
+template <int W, int H, bool RARE>
 __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint32_t e, uint32_t lane,
                                            uint32_t (&t)[4], uint32_t (&u)[4], uint32_t (&h)[4], EnvS &s,
                                            u64 *reach_e)
@@ -113,12 +113,22 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
     const bool active = lane < (uint32_t)(CELLS / 4);
     const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1);
     u64 onborder = 0;
+    uint32_t water = 0;                                              // bit j: cell j of this lane is a river cell
+    bool rivers = false;
+    if constexpr (RARE) {
+        rivers = cold->p.make_rivers != 0;                           // reset_map :69-95
+        if (rivers)
+            river_cells(key, W, H, [&](int x, int y) {
+                const uint32_t d = (uint32_t)(y * W + x) - 4u * lane;
+                water |= d < 4u ? 1u << d : 0u;
+            });
+    }
     static_for<4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const uint32_t q = 4u * lane + j;
         int32_t fuel = fuel_lo;
         if (span > 1u) fuel += (int32_t)below(key.draw(16u + q), span);
-        uint32_t ty = WF_GRASS, heat = 0;
+        uint32_t ty = ((water >> j) & 1u) ? (uint32_t)WF_WATER : (uint32_t)WF_GRASS, heat = 0;
         if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }         // set_fire_to :233-246
         if (q == qs) ty = WF_DIRT;                                    // Agent.__init__ digs :111-113
         bool extra = false;
@@ -131,7 +141,7 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
     });
     // Border reachability of a fresh grid is known in closed form: every cell except the
     // agent's (dug) spawn cell - removing one cell cannot disconnect a grid - so the first
-    // containment test of the episode needs no flood.
+    // containment test of the episode needs no flood.  (Not with a river: the board stays invalid.)
     if (lane == 0) {
         u64 rb[4];
         static_for<4>([&](auto J) {
@@ -144,7 +154,7 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
     }
     s.ax = sx;
     s.ay = sy;
-    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | WF_F_REACH_VALID | (onborder ? WF_F_BORDER : 0u);
+    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | (rivers ? 0u : (uint32_t)WF_F_REACH_VALID) | (onborder ? WF_F_BORDER : 0u);
     s.episode += 1;
     s.tick = 0;
 }
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256) void wf_reset_wave(const WfArgs a)
         s.episode = rfl(ev.z);
         s.tick = 0;
         uint32_t t[4], u[4], h[4];
-        reset_regs<W, H>(a.cold, a.reset_seed, e, lane, t, u, h, s, a.reach + (size_t)e * 4);
+        reset_regs<W, H, true>(a.cold, a.reset_seed, e, lane, t, u, h, s, a.reach + (size_t)e * 4);
         const uint32_t qa = s.ay * W + s.ax;
         uint32_t r[4];
 #pragma unroll
@@ -336,7 +346,8 @@ StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
     p.G = wf_pick_group_for(W, H, num_cus, a.batch, k);
     const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
     if (a.group > 0) p.G = a.group < gmax ? a.group : gmax;
-    const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096;
+    // (the workgroup-shared experiment exists for the reference's default options only)
+    const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096 && !(a.hot_flags & WF_HOT_RARE);
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
     if constexpr (HasRows<W, H>::value) {
         constexpr int EPW = RG<W, H, HasRows<W, H>::S>::EPW;
@@ -354,11 +365,14 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
     const int cap = num_cus * 8;            // up to 32 resident waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    // dig toggle / rivers (off in the reference's defaults) run in their own instantiations of the step kernels
+    const bool rare = (a.hot_flags & WF_HOT_RARE) != 0;
     if (reset)
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.n_steps > 1 && !k.multi_rows)
-        hipLaunchKernelGGL((wf_step_wave<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
-    else {
+    else if (a.n_steps > 1 && !k.multi_rows) {
+        if (rare) hipLaunchKernelGGL((wf_step_wave<W, H, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wf_step_wave<W, H, true, false>), dim3(blocks), dim3(256), 0, s, a);
+    } else {
         const StepPlan p = plan_single<W, H>(a, k, num_cus);
         if (a.n_steps > 1 && p.kind != STEP_ROWS) return hipErrorInvalidValue;   // only the rows kernel has the step loop
         WfArgs g = a;
@@ -367,18 +381,21 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         const dim3 grid_private((waves + 3) / 4), grid_shared((a.batch + 63) / 64), block_shared(64 * (64 / p.G));
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
-            if (p.kind == STEP_ROWS && a.n_steps > 1) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true>), grid_private, dim3(256), 0, s, g);
-            if (p.kind == STEP_ROWS && a.n_steps <= 1) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false>), grid_private, dim3(256), 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, true>), grid_private, dim3(256), 0, s, g);
             if (p.kind == STEP_ROWS_SHARED) {
                 // WF_SHARED=N with N in {2,4,8}: N waves share the agent phases (N*G <= 64 environments per workgroup)
                 int nw = k.shared;
                 if (nw < 2 || nw * p.G > 64) nw = 64 / p.G;
                 const int per_wg = nw * p.G;
-                hipLaunchKernelGGL((wf_step_rows<W, H, S, true, false>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
+                hipLaunchKernelGGL((wf_step_rows<W, H, S, true, false, false>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
             }
         }
-        if (p.kind == STEP_GROUP) hipLaunchKernelGGL((wf_step_group<W, H, false>), grid_private, dim3(256), 0, s, g);
-        if (p.kind == STEP_GROUP_SHARED) hipLaunchKernelGGL((wf_step_group<W, H, true>), grid_shared, block_shared, 0, s, g);
+        if (p.kind == STEP_GROUP && !rare) hipLaunchKernelGGL((wf_step_group<W, H, false, false>), grid_private, dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP && rare) hipLaunchKernelGGL((wf_step_group<W, H, false, true>), grid_private, dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP_SHARED) hipLaunchKernelGGL((wf_step_group<W, H, true, false>), grid_shared, block_shared, 0, s, g);
     }
     return hipGetLastError();
 }

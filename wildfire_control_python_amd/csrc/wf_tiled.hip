@@ -573,10 +573,20 @@ __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const 
     const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
     uint32_t *pe = a.planes + (size_t)e * cells;
     bool border_fire = false;
+    // reset_map's river (environment.py:69-95): column of the water cell of every row (0xffff: none), walked once
+    __shared__ uint16_t river_x[WF_RIVER_MAX_H];
+    const bool rivers = cold->p.make_rivers != 0;
+    if (rivers) {
+        for (uint32_t r = threadIdx.x; r < H; r += 256u) river_x[r] = 0xffffu;
+        __syncthreads();
+        if (threadIdx.x == 0) river_cells(key, (int)W, (int)H, [&](int x, int y) { river_x[y] = (uint16_t)x; });
+        __syncthreads();
+    }
     for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
         uint32_t fuel = (uint32_t)fuel_lo;
         if (span > 1u) fuel += below(key.draw(16u + q), span);
         uint32_t ty = WF_GRASS, heat = 0, ag = 0;
+        if (rivers && river_x[q / W] == q % W) ty = WF_WATER;
         if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
         if (q == qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
         if (ppm && ty == WF_GRASS && below(key.draw(16u + cells + q), 1000000u) < ppm) {

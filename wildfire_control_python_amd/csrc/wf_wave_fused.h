@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 #ifndef WF_LB
 #define WF_LB 6   // minimum waves per SIMD the register allocator must leave room for
 #endif
-template <int W, int H, bool FUSED>
+template <int W, int H, bool FUSED, bool RARE>
 __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
 {
     constexpr int CELLS = W * H, LANES = CELLS / 4;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                     uint32_t e_pin = e;
                     asm volatile("" : "+s"(cold), "+s"(e_pin));
                     cold_ptr cc = (cold_ptr)(uintptr_t)cold;
-                    reset_regs<W, H>(cold, cc->p.seed, e_pin + a.env_base, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);   // stream keyed by the context index
+                    reset_regs<W, H, RARE>(cold, cc->p.seed, e_pin + a.env_base, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);   // stream keyed by the context index
                     ax = s.ax; ay = s.ay; fl = s.fl; episode = s.episode; tick = s.tick;
                     {   // the fresh bitboards were written with vector stores: keep them in registers,
                         // never re-read them through the scalar cache inside this launch
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 ay += moved * (ny - ay);
                 uint32_t ta = tcur + moved * (td - tcur);                              // type under the agent
                 // ---- Agent.toggle_digging (forest_fire.py:35-36, environment.py:136-138): rare
-                if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
                     if (rfl(act == 4u ? 1u : 0u)) {
                         fl ^= WF_F_DIGGING;
                         // dig() under the agent: a BURNING cell too, which stays in burning_cells under its
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
                         const uint32_t runs = (uint32_t)__popc(ring & ~rot);
                         recompute |= dug & (onb | (runs >> 1) | (runs >> 2));
-                        if (a.hot_flags & WF_HOT_DIG_TOGGLE)      // digging next to burning dirt may cut its last link (see wf_step_group)
+                        if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE))      // digging next to burning dirt may cut its last link (see wf_step_group)
                             recompute |= dug & ((uint32_t)__ballot(ty == (uint32_t)WF_DIRT_BURNING && !rout && lane < 8u && !(lane & 1u)) ? 1u : 0u);
                     }
                     if (rfl(recompute)) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         for (int j = 0; j < 4; ++j) PASS[j] = ~__ballot(t[j] >= WF_DIRT);
                         static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                         flood<W, H>(RB, PASS);
-                        if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                        if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
                             u64 Z[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) Z[j] = __ballot(t[j] == (uint32_t)WF_DIRT_BURNING);

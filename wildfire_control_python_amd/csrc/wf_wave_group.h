@@ -29,7 +29,7 @@ struct EnvRegs {
 // Phase A for the environment of this lane: Agent.move / toggle / death, the containment ring
 // verdict, and the touched bytes applied to the grid in memory.  Returns the env's registers;
 // Pv = PB_* bits for phase B (bit 0 = the env was running when the step began).
-template <int W, int H, int VB>
+template <int W, int H, int VB, bool RARE>
 __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lane_env, const uint32_t ek, const bool do_update)
 {
     constexpr int CELLS = W * H;
@@ -54,7 +54,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
     // cell that would be dug (ring test, see "Containment shortcut" above)
     const uint32_t td = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + qd * 4u));
     const uint32_t tcur = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + qa * 4u));
-    const bool toggling = (a.hot_flags & WF_HOT_DIG_TOGGLE) != 0;
+    const bool toggling = RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE) != 0;
     const uint32_t istog = toggling ? (act == 4u ? 1u : 0u) : 0u;
     // cell that may be dug: destination of a move, or the own cell when digging is toggled on
     const uint32_t xd = istog ? ax : (inb ? nx : ax), yd = istog ? ay : (inb ? ny : ay);
@@ -74,7 +74,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
             const uint32_t nq = off ? 0u : qx + (uint32_t)(DY[r] * W + DX[r]);
             const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
             ring |= ((off ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
-            if (toggling) zring |= ((off ^ 1u) & (ty == (uint32_t)WF_DIRT_BURNING ? 1u : 0u)) << r;
+            if constexpr (RARE) zring |= ((off ^ 1u) & (ty == (uint32_t)WF_DIRT_BURNING ? 1u : 0u)) << r;
         }
         // which 4-neighbours (ring bits 0,2,4,6 = N,E,S,W) are border cells themselves
         const uint32_t ex = x0 | xl, ey = y0 | yl;
@@ -98,7 +98,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
         const uint32_t dugt = (fl >> 2) & ((DIG_SET | 2u) >> tcur) & 1u;
         dug = tg ? dugt : dug;
         qd = tg ? qa : qd;
-        dugtype = (tg & (2u >> tcur) & 1u) ? (uint32_t)WF_DIRT_BURNING : dugtype;
+        if constexpr (RARE) dugtype = (tg & (2u >> tcur) & 1u) ? (uint32_t)WF_DIRT_BURNING : dugtype;
     }
     ta += dug * ((uint32_t)WF_DIRT - ta);
     if (do_update) {   // forest_fire.py:87 drop dead agents (Agent.is_dead environment.py:116-120)
@@ -172,7 +172,7 @@ __device__ __forceinline__ void group_phase_c(const WfArgs &a, const EnvRegs &S,
 //   lanes busy instead of G of them), the registers travel through LDS, the 64/G waves each run
 //   phase B for G environments, and whichever wave finishes last runs phase C for all 64.  This
 //   divides the per-environment instruction cost of phases A and C by 64/G.
-template <int W, int H, bool SHARED>
+template <int W, int H, bool SHARED, bool RARE>
 __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_step_group(const WfArgs a)
 {
     constexpr int CELLS = W * H, LANES = CELLS / 4;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
     uint32_t Pv;
     if constexpr (SHARED) {
         if (wv == 0) {
-            S = group_phase_a<W, H, 7>(a, lane_env, ek, do_update);
+            S = group_phase_a<W, H, 7, RARE>(a, lane_env, ek, do_update);
             sS[S_POS][lane] = S.ax | (S.ay << 16);
             sS[S_FL][lane] = S.fl;
             sS[S_EP][lane] = S.episode;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
         __syncthreads();                                     // workgroup-scope release/acquire: same CU, same L1
         Pv = sS[S_P][wv * G + (lane < G ? lane : 0u)];       // lane k <-> k-th environment of this wave's group
     } else {
-        S = group_phase_a<W, H, 7>(a, lane_env, ek, do_update);
+        S = group_phase_a<W, H, 7, RARE>(a, lane_env, ek, do_update);
         Pv = S.Pv;
         // the byte stores above must have landed before phase B reads those grids back
         __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0) lgkmcnt(0) expcnt(0)
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     cold_ptr cc = (cold_ptr)(uintptr_t)cold;
                     uint32_t t[4], u[4], h[4];
                     // the stream is keyed by the env's index in the context, not in this (possibly split) launch
-                    reset_regs<W, H>(cold, cc->p.seed, e_pin + a.env_base, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
+                    reset_regs<W, H, RARE>(cold, cc->p.seed, e_pin + a.env_base, lane, t, u, h, s, a.reach + (size_t)e_pin * 4);
                     const uint32_t qs = s.ay * W + s.ax;
                     uint32_t r[4];
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // reduce_fuel (environment.py:297-307)
-                    const u64 F = __ballot((c[j] & 3u) == 1u);                         // burning: fire or burning dirt
+                    const u64 F = __ballot(burning<RARE>(c[j]));                         // burning: fire or burning dirt
                     STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                     // fuel -= 1 and fire -> burnt, unless still burning (type stays fire)
                     const uint32_t d = lanebit(STILL[j]) ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                 R |= __ballot((ign_bits & bgeo) != 0u) ? RB_BORDER : 0u;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot((c[j] & 3u) == 1u);
+                for (int j = 0; j < 4; ++j) FIRE[j] = __ballot(burning<RARE>(c[j]));
             }
             const bool anyfire = (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) != 0;
             R |= anyfire ? RB_ANYFIRE : 0u;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     for (int j = 0; j < 4; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
                     static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                     flood<W, H>(RB, PASS);
-                    if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                    if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
                         u64 Z[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) Z[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_DIRT_BURNING);

@@ -142,7 +142,7 @@ __device__ __forceinline__ void store_dwords(char *p, const uint32_t *r)
 // same law as reset_regs).  Every lane computes the cells "as if" it belonged to that
 // environment (y, xs = its row and first column); the lanes of HM (`mine`) keep them.
 // Returns the spawn cell in (s.ax, s.ay); writes the 4-cells-per-lane closed-form board too.
-template <int W, int H, int S>
+template <int W, int H, int S, bool RARE>
 __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint32_t e_ctx, uint32_t y, uint32_t xs,
                                            uint32_t bgeo, u64 HM, bool mine, uint32_t (&c)[RG<W, H, S>::CPL], EnvS &s,
                                            u64 *reach_e, bool writer)
@@ -160,12 +160,22 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
     const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1);
     const uint32_t q0 = y * W + xs;
     u64 onborder = 0;
+    uint32_t water = 0;                                              // bit j: slot j of this lane is a river cell
+    bool rivers = false;
+    if constexpr (RARE) {
+        rivers = cold->p.make_rivers != 0;                           // reset_map :69-95
+        if (rivers)
+            river_cells(key, W, H, [&](int x, int yy) {
+                const uint32_t d = (uint32_t)(yy * W + x) - q0;
+                water |= d < (uint32_t)CPL ? 1u << d : 0u;
+            });
+    }
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         const uint32_t q = q0 + (uint32_t)j;
         int32_t fuel = fuel_lo;
         if (span > 1u) fuel += (int32_t)below(key.draw(16u + q), span);
-        uint32_t ty = WF_GRASS, heat = 0;
+        uint32_t ty = ((water >> j) & 1u) ? (uint32_t)WF_WATER : (uint32_t)WF_GRASS, heat = 0;
         if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }         // set_fire_to :233-246
         if (q == qs) ty = WF_DIRT;                                    // Agent.__init__ digs :111-113
         bool extra = false;
@@ -188,14 +198,15 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
     }
     s.ax = sx;
     s.ay = sy;
-    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | WF_F_REACH_VALID | WF_F_REACH_ROWS |
+    // (with a river the closed-form boards do not hold: the first containment test of the episode floods)
+    s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | (rivers ? 0u : (uint32_t)(WF_F_REACH_VALID | WF_F_REACH_ROWS)) |
            (onborder ? WF_F_BORDER : 0u);
     s.episode += 1;
     s.tick = 0;
 }
 
 // MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
-template <int W, int H, int S, bool SHARED, bool MULTI>
+template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE>
 __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_LB_ROWS) void wf_step_rows(const WfArgs a0)
 {
     using R = RG<W, H, S>;
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
     const uint32_t ek = A0 + (lane_env ? lane : 0u);
     const uint32_t ai = SHARED ? lane : gi0 + (lane_env ? lane : 0u);   // LDS slot of this env-lane
     if (!SHARED || wv == 0) {
-        const EnvRegs S0 = group_phase_a<W, H, 8>(a, lane_env, ek, do_update);
+        const EnvRegs S0 = group_phase_a<W, H, 8, RARE>(a, lane_env, ek, do_update);
         if (lane_env) {
             sS[S_POS][ai] = S0.ax | (S0.ay << 16);
             sS[S_FL][ai] = S0.fl;
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
                             uint32_t y_pin = y, xs_pin = xs, bgeo_pin = bgeo, hh_pin = hh;     // keep the rare path's per-lane
                             asm volatile("" : "+s"(cold), "+s"(e_pin), "+v"(y_pin), "+v"(xs_pin), "+v"(bgeo_pin), "+v"(hh_pin));   // work inside this branch
                             cold_ptr cc = (cold_ptr)(uintptr_t)cold;
-                            reset_rows<W, H, S>(cold, cc->p.seed, e_pin + a.env_base, y_pin, xs_pin, bgeo_pin, R::hm(h), hh_pin == (uint32_t)h, c, s,
+                            reset_rows<W, H, S, RARE>(cold, cc->p.seed, e_pin + a.env_base, y_pin, xs_pin, bgeo_pin, R::hm(h), hh_pin == (uint32_t)h, c, s,
                                                 a.reach + (size_t)e_pin * 4, lane == (uint32_t)(h * PITCH));
                             chg |= hh == (uint32_t)h ? 1u : 0u;
                             // rows board in closed form: every cell of the environment but the spawn cell
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
                         // reduce_fuel (environment.py:297-307); finished environments hold no "fire" here
-                        const u64 F = __ballot((c[j] & 3u) == 1u) & RUNM;               // burning: fire or burning dirt
+                        const u64 F = __ballot(burning<RARE>(c[j])) & RUNM;               // burning: fire or burning dirt
                         STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                         const bool st = lanebit(STILL[j]);
                         sv[j] = st ? 1u : 0u;
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
                 } else {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
-                        const u64 FJ = __ballot((c[j] & 3u) == 1u) & RUNM;
+                        const u64 FJ = __ballot(burning<RARE>(c[j])) & RUNM;
                         FIREALL |= FJ;
                         HITS |= FJ & RBG[j];
                     }
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
                     for (int j = 0; j < CPL; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
                     static_for<CPL>([&](auto J) { constexpr int j = decltype(J)::value; NB[j] = R::template BORDER<j> & PASS[j]; });
                     flood_rows<W, H, S>(NB, PASS);
-                    if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+                    if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
                         // burning dirt reaches the border through its 4-neighbours (see add_blocked_burning)
                         u64 ZB[CPL], ADD[CPL];
 #pragma unroll
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) {
                         RBG[j] = (RBG[j] & ~NEEDM) | (NB[j] & NEEDM);
-                        HITS |= __ballot((c[j] & 3u) == 1u) & RUNM & RBG[j];
+                        HITS |= __ballot(burning<RARE>(c[j])) & RUNM & RBG[j];
                     }
                     rb_dirty = true;
                 }
