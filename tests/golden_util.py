@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def fixture_files(size=None):
-    pat = f"ref_{size}_*.npz" if size else "ref_*.npz"
+    pat = f"ref_{size}_*.npz" if size else "ref_[0-9]*_*.npz"      # episode fixtures (not ref_reset_stats_*.npz)
     return sorted(glob.glob(os.path.join(GOLDEN, pat)))
 
 
