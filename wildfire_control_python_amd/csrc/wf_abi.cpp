@@ -534,14 +534,16 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.n_steps = 1;
             a.update_mask = (update_mask >> st) & 1ull;
             u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H) * 8 : nullptr;
-            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, halo, c->p.seed,
-                                          i == 0 ? c->stream : c->side[i - 1]));
+            hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
+            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, halo, c->p.seed, si));
+            // World.get_state() of the final state: every share writes its own environments on its own stream
+            // (no join of the shares for it)
+            if (d_obs && st == n_steps - 1)
+                HIP_TRY(c, wf_launch_get_state(a.planes_out, d_obs + (size_t)lo * cells * 3, hi - lo, c->H, c->W, si));
         }
         if (c->planes_alt) { uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t; }   // ping-pong
     }
     if (split) c->side_pending = true;
-    if (d_obs) JOIN(c);
-    if (d_obs) HIP_TRY(c, wf_launch_get_state(c->planes, d_obs, c->batch, c->H, c->W, c->stream));
     return WF_OK;
 }
 

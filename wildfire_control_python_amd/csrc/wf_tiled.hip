@@ -181,10 +181,20 @@ __device__ __forceinline__ void still_masks(const uint4 &r, u64 (&S)[4])
 // switches (update or not, containment test or not) are template parameters of the sweep.
 struct TiledAcc { uint32_t anyfire, bhit, healthy, reach_hit; u64 ign_x0, ign_xl; };
 
+// Destination of the in-place stores of one environment: a buffer descriptor over its cells + this lane's byte offset.
+// The stores can carry cache-policy bits (WF_TILED_STORE_AUX 16 = sc1: written through the XCD's L2 instead of left
+// dirty for the write-back at the kernel boundary, MI355X_MICROARCH.md row "boundary").  Measured at 1 024 x 256x256:
+// 102.8 vs 105.7 us per step with two launch sequences per step, 127.3 vs 126.4 with one: within noise, so plain stores.
+#ifndef WF_TILED_STORE_AUX
+#define WF_TILED_STORE_AUX 0
+#endif
+struct TiledDst { __amdgpu_buffer_rsrc_t rsrc; uint32_t lane_off; };
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+
 template <bool STEP, bool REACH>
 __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, uint32_t ign, bool active, const uint4 &cur,
                                           const u64 (&Sp)[4], const u64 (&Sc)[4], const u64 (&Sn)[4], const u64 *reach_e,
-                                          uint4 *dst, TiledAcc &A)
+                                          const TiledDst &dst, TiledAcc &A)
 {
     uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
     u64 FIRE[4], GR[4];
@@ -231,13 +241,13 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
     A.healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
     if constexpr (STEP) {
         if (active && ((c[0] ^ cur.x) | (c[1] ^ cur.y) | (c[2] ^ cur.z) | (c[3] ^ cur.w)))
-            dst[r * LW] = make_uint4(c[0], c[1], c[2], c[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v4u32{ c[0], c[1], c[2], c[3] }, dst.rsrc, (int)(dst.lane_off + r * LW * 16u), 0, WF_TILED_STORE_AUX);
     }
 }
 
 template <bool STEP, bool REACH>
 __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, bool active,
-                                            const uint4 *src, uint4 *dst, const uint4 &first, const u64 (&Sf)[4],
+                                            const uint4 *src, const TiledDst &dst, const uint4 &first, const u64 (&Sf)[4],
                                             const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, TiledAcc &A)
 {
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4] in this kernel's mask layout
     // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
-    uint4 *dst = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+    const TiledDst dst = { __builtin_amdgcn_make_buffer_rsrc(a.planes + (size_t)e * H * W, 0, (int)(H * W * 4u), 0x00020000), lane * 16u };
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
 
     // ---- prologue: masks of the strip's first and last row -> LDS

@@ -138,6 +138,28 @@ __device__ __forceinline__ void store_dwords(char *p, const uint32_t *r)
     }
 }
 
+// The same N dwords through a buffer store that carries cache-policy bits (aux 16 = sc1: agent scope, i.e. written
+// THROUGH the XCD's L2).  A plain store leaves the line dirty in L2, and everything still dirty when the kernel ends
+// is written back at the kernel boundary, where nothing overlaps it (MI355X_MICROARCH.md, row "boundary":
+// + B / 6 TB/s for B dirty bytes - ~27 MB per 65 536 x 14x14 step); write-through moves that traffic under the kernel.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v3u32 __attribute__((ext_vector_type(3)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+template <int N, int AUX>
+__device__ __forceinline__ void store_dwords_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t off, const uint32_t *r)
+{
+    if constexpr (N >= 4) {
+        __builtin_amdgcn_raw_buffer_store_b128(v4u32{ r[0], r[1], r[2], r[3] }, rsrc, (int)off, 0, AUX);
+        if constexpr (N > 4) store_dwords_buf<N - 4, AUX>(rsrc, off + 16u, r + 4);
+    } else if constexpr (N == 3) {
+        __builtin_amdgcn_raw_buffer_store_b96(v3u32{ r[0], r[1], r[2] }, rsrc, (int)off, 0, AUX);
+    } else if constexpr (N == 2) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u32{ r[0], r[1] }, rsrc, (int)off, 0, AUX);
+    } else if constexpr (N == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(r[0], rsrc, (int)off, 0, AUX);
+    }
+}
+
 // World.reset() of ONE environment of the iteration into the rows layout (same stream and
 // same law as reset_regs).  Every lane computes the cells "as if" it belonged to that
 // environment (y, xs = its row and first column); the lanes of HM (`mine`) keep them.
@@ -207,7 +229,11 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
 
 // MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
 template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE>
-__global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_LB_ROWS) void wf_step_rows(const WfArgs a0)
+// Waves per SIMD as a RANGE (7..8): asked for 8 as a minimum, the register allocator budgets 80 scalar registers
+// per wave and parks ~140 scalar values per wave in VGPR lanes (v_writelane / v_readlane) on the hot path; a minimum of
+// 7 allows it 94, a third of those spills go, and the kernel still needs only 62 VGPRs = 8 waves per SIMD
+__global__ __launch_bounds__(SHARED ? 512 : 256)
+__attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN, MULTI ? WF_LB_ROWS_MULTI : WF_LB_ROWS), amdgpu_num_sgpr(102))) void wf_step_rows(const WfArgs a0)
 {
     using R = RG<W, H, S>;
     constexpr int CELLS = W * H, CPL = R::CPL, LPE = R::LPE, PITCH = R::PITCH, EPW = R::EPW;
@@ -256,6 +282,8 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
     const uint32_t ign = (uint32_t)a.ignite_count;
     const bool do_update = (a.update_mask & 1ull) != 0;
     char *planes_b = reinterpret_cast<char *>(a.planes);
+    // (this launch's planes; 32-bit byte offsets - wf_create keeps a context's planes below 4 GiB)
+    const __amdgpu_buffer_rsrc_t planes_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.planes, 0, (int)(batch * ENV_BYTES), 0x00020000);
     __shared__ uint32_t sS[7][SHARED ? 64 : 128];            // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
     enum { S_POS = 0, S_FL = 1, S_EP = 2, S_TICK = 3, S_P = 4, S_R = 5, S_CNT = 6 };
 
@@ -469,7 +497,10 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, MULTI ? WF_LB_ROWS_MULTI : WF_L
                 Rl = lanebit(WASRESET) ? (uint32_t)RB_WASRESET : Rl;
                 if (l == (uint32_t)(LPE - 1)) sS[S_R][idx] = Rl;
                 // most cells do not change in a tick: a lane whose row piece is unchanged writes nothing
-                if (chg || !WF_SKIP_CLEAN) store_dwords<CPL>(planes_b + eoff, c);
+                if (chg || !WF_SKIP_CLEAN) {
+                    if constexpr (WF_STORE_AUX != 0) store_dwords_buf<CPL, WF_STORE_AUX>(planes_rsrc, eoff, c);
+                    else store_dwords<CPL>(planes_b + eoff, c);
+                }
                 if (a.obs) {
                     // World.get_state() of the iteration's environments: byte triples into the LDS image at
                     // their transposed offsets, then the image leaves as 16-byte stores
