@@ -46,6 +46,7 @@ struct wf_ctx {
     uint8_t *d_mode = nullptr;        // big-grid families: per-env mode of the current step
     uint32_t *d_acc = nullptr;        // big-grid families: per-env reduction words
     int staged_steps = 0;
+    void *dbg_timing = nullptr;       // measurement builds (WF_WAVE_TIMING) only
     WfSpawn spawn;
     int last_hip = 0;
 };
@@ -124,6 +125,9 @@ WfArgs base_args(const wf_ctx *c)
     a.hot_flags = (c->p.containment ? WF_HOT_CONTAINMENT : 0) | (c->p.auto_reset ? WF_HOT_AUTO_RESET : 0) |
                   (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0) | (c->p.make_rivers ? WF_HOT_RIVERS : 0);
     a.group = c->knobs.group;          // experiment knob: cap on environments per wave of the single-step kernel
+#ifdef WF_WAVE_TIMING
+    a.mask = static_cast<const uint8_t *>(c->dbg_timing);
+#endif
     a.default_reward = c->p.default_reward;
     a.death_penalty = c->p.death_penalty;
     a.contained_bonus = c->p.contained_bonus;
@@ -654,6 +658,11 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
     if (n_steps == 1) return c->n_parts;
     return multi_rows_call(c, n_steps) ? c->n_parts : c->n_parts * n_steps;
 }
+
+#ifdef WF_WAVE_TIMING
+// measurement builds only: device buffer of 5 x u64 per wave of a step launch (see wf_step_rows)
+int wf_debug_timing(wf_ctx *c, void *d_buf) { if (!c) return WF_ERR_ARG; c->dbg_timing = d_buf; return WF_OK; }
+#endif
 
 int wf_reload_env(wf_ctx *c)
 {

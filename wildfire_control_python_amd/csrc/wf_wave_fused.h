@@ -42,8 +42,11 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
                           // 20.0 vs 20.5 us per 65 536-env step with two launches per step, but 28.0 vs 25.7 with one, 36.0 vs 30.2 at
                           // 125 000 envs and 318 vs 291 at 1 M - sparse 28-byte pieces written through cost more than the write-back saves)
 #endif
+#ifndef WF_PROGRESS_PRIO
+#define WF_PROGRESS_PRIO 0   // rows kernel: a wave lowers its issue priority as it gets ahead (see set_progress_prio; measured: off is faster)
+#endif
 #ifndef WF_ROWS_WAVES_MIN
-#define WF_ROWS_WAVES_MIN (WF_LB_ROWS - 1)   // see wf_step_rows: the scalar-register budget follows the minimum
+#define WF_ROWS_WAVES_MIN WF_LB_ROWS   // see wf_step_rows
 #endif
 #ifndef WF_STORE_WAIT
 #define WF_STORE_WAIT 1   // 0: private-phase kernels skip the wait for phase A byte stores (no measurable gain: 22.4-22.7 us either way)

@@ -227,11 +227,34 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
     s.tick = 0;
 }
 
+// Issue priority by progress.  The SIMD arbitrates VALU issue between its resident waves by priority, then AGE
+// (MI355X_MICROARCH.md, "Two waves per SIMD"): at equal priority the oldest wave runs nearly unimpeded and the
+// youngest gets the leftovers.  With one generation of waves per launch (65 536 envs = 8 192 waves = every wave slot of
+// the chip) that turns the eight waves of a SIMD into a staircase - tools/wave_timeline.py: first wave done after
+// 8.5 us, last after 25, the tail of each SIMD running one or two waves deep where a single wave is bound by its own
+// dependency chain (~12 cycles per instruction).  Experiment (WF_PROGRESS_PRIO=1): a wave LOWERS its priority as it gets
+// ahead (phase A and the first quarter of its iterations at 3, then 2, 1, 0).  It does what it says - all eight waves of
+// a SIMD then end within 3 us of each other - but the SIMD is not done earlier: eight waves in the SAME phase compete
+// for the same pipe, the staircase had them in different phases.  23.7 vs 25.3 us per step as one launch, but 22.3 vs
+// 20.3 with the two half-batch launches, 34.9 vs 30.8 at 125 000 envs, 66.7 vs 60.3 at 262 144: off by default.
+template <int LEVEL>
+__device__ __forceinline__ void set_progress_prio(uint32_t done, uint32_t total)
+{
+#if WF_PROGRESS_PRIO
+    const uint32_t q = (done * 4u) / total;                 // wave-uniform
+    if (q == 0u) __builtin_amdgcn_s_setprio(3);
+    else if (q == 1u) __builtin_amdgcn_s_setprio(2);
+    else if (q == 2u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
 template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE>
-// Waves per SIMD as a RANGE (7..8): asked for 8 as a minimum, the register allocator budgets 80 scalar registers
-// per wave and parks ~140 scalar values per wave in VGPR lanes (v_writelane / v_readlane) on the hot path; a minimum of
-// 7 allows it 94, a third of those spills go, and the kernel still needs only 62 VGPRs = 8 waves per SIMD
+// Waves per SIMD: minimum = maximum = 8.  (A minimum of 7 gives the register allocator 94 scalar registers instead of
+// 80 and removes a third of the scalar spills to VGPR lanes, and the compiler still reports 8 waves per SIMD - but a
+// wave's 94 SGPRs are allocated as 112, 800 / 112 = 7: tools/wave_timeline.py showed exactly one workgroup in eight
+// starting 10 us late.  Same step time either way; 8 resident waves is what the launch geometry assumes.)
 __global__ __launch_bounds__(SHARED ? 512 : 256)
 __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN, MULTI ? WF_LB_ROWS_MULTI : WF_LB_ROWS), amdgpu_num_sgpr(102))) void wf_step_rows(const WfArgs a0)
 {
@@ -262,6 +285,15 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     // n_steps > 1: the wave simply steps its environments again (each wave owns its environments, so nothing has
     // to be synchronised across waves); this spares a kernel boundary - 2.8 us of dispatch - per step and launch.
     static_assert(!(SHARED && MULTI), "the workgroup-shared variant steps once");
+#if WF_PROGRESS_PRIO
+    if constexpr (!SHARED && !MULTI) __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef WF_WAVE_TIMING   // measurement build (tools/wave_timeline.py): 100 MHz wall clock at the phase borders of every wave
+    const u64 wt0 = wall_clock64();
+    u64 wtA = 0, wtB = 0;
+    uint32_t wt_reset = 0, wt_flood = 0, wt_flood_it = 0;
+    u64 wt_it[4] = { 0, 0, 0, 0 };
+#endif
     const uint32_t nst = MULTI ? (uint32_t)a0.n_steps : 1u;
     for (uint32_t st = 0; st < nst; ++st) {
     WfArgs a = a0;
@@ -310,6 +342,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     if constexpr (SHARED) __syncthreads();
     else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
+#ifdef WF_WAVE_TIMING
+    wtA = wall_clock64();
+#endif
     // ================= phase B: EPW environments at a time, lanes = row pieces =================
     const uint32_t hh = lane / (uint32_t)PITCH, l = lane - hh * (uint32_t)PITCH;
     const bool cell_lane = hh < (uint32_t)EPW && l < (uint32_t)LPE;
@@ -334,6 +369,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         // board of the iteration's group (context-level group index), advanced with the loop
         u64 *board = a.reach_rows + (size_t)((a.env_base + e0) / (uint32_t)EPW) * CPL;
         for (uint32_t kb = 0; kb < ng; kb += (uint32_t)EPW, off += (uint32_t)EPW * ENV_BYTES, board += CPL) {
+            if constexpr (!SHARED && !MULTI) set_progress_prio<0>(kb, G);
             if (kb + hh < ng) {
                 const uint32_t eoff = off + hh * ENV_BYTES;
                 uint32_t c[CPL];
@@ -355,6 +391,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                 if (RUNM != VM && (a.hot_flags & WF_HOT_AUTO_RESET)) {
                     // ---- rare: finished environments start a new episode instead of stepping
                     WASRESET = VM & ~RUNM;
+#ifdef WF_WAVE_TIMING
+                    wt_reset += (uint32_t)__popcll(WASRESET & R::WRITERS);
+#endif
                     static_for<EPW>([&](auto HH) {
                         constexpr int h = decltype(HH)::value;
                         if (WASRESET & R::hm(h)) {
@@ -444,6 +483,25 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
                     static_for<CPL>([&](auto J) { constexpr int j = decltype(J)::value; NB[j] = R::template BORDER<j> & PASS[j]; });
+#ifdef WF_WAVE_TIMING
+                    wt_flood += 1;
+                    {   // count the relaxation sweeps of this flood (same loop as flood_rows, on a copy)
+                        u64 T[CPL];
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) T[j] = NB[j];
+                        for (int it = 0; it < W * H; ++it) {
+                            u64 any = 0;
+                            static_for<CPL>([&](auto J) {
+                                constexpr int j = decltype(J)::value;
+                                const u64 add = ((T[j] << S) | (T[j] >> S) | rg_lf<W, H, S, j>(T) | rg_rt<W, H, S, j>(T)) & PASS[j] & ~T[j];
+                                T[j] |= add;
+                                any |= add;
+                            });
+                            wt_flood_it += 1;
+                            if (!any) break;
+                        }
+                    }
+#endif
                     flood_rows<W, H, S>(NB, PASS);
                     if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
                         // burning dirt reaches the border through its 4-neighbours (see add_blocked_burning)
@@ -497,6 +555,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                 Rl = lanebit(WASRESET) ? (uint32_t)RB_WASRESET : Rl;
                 if (l == (uint32_t)(LPE - 1)) sS[S_R][idx] = Rl;
                 // most cells do not change in a tick: a lane whose row piece is unchanged writes nothing
+#ifdef WF_WAVE_TIMING
+                if ((kb >> 1) < 4u) wt_it[kb >> 1] = wall_clock64();
+#endif
                 if (chg || !WF_SKIP_CLEAN) {
                     if constexpr (WF_STORE_AUX != 0) store_dwords_buf<CPL, WF_STORE_AUX>(planes_rsrc, eoff, c);
                     else store_dwords<CPL>(planes_b + eoff, c);
@@ -531,6 +592,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         }
     }
 
+#ifdef WF_WAVE_TIMING
+    wtB = wall_clock64();
+#endif
     // ================= phase C: lanes = environments =================
     if constexpr (SHARED) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -553,5 +617,18 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         const uint32_t Rv = sS[S_R][ai];
         group_phase_c<W, H, 8>(a, S1, Rv, lane_env, ek, do_update);
     }
+#ifdef WF_WAVE_TIMING
+    if (a0.mask && lane == 0) {      // (the reset mask pointer is unused by step launches: the timing buffer rides on it)
+        __builtin_amdgcn_s_waitcnt(0);
+        u64 *rec = reinterpret_cast<u64 *>(const_cast<uint8_t *>(a0.mask)) + (size_t)((a0.env_base + e0) / G) * 10;
+        rec[6] = wt_it[0]; rec[7] = wt_it[1]; rec[8] = wt_it[2]; rec[9] = wt_it[3];
+        uint32_t xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        rec[5] = hwid;
+        rec[0] = wt0; rec[1] = wtA; rec[2] = wtB; rec[3] = wall_clock64();
+        rec[4] = (u64)(wt_reset & 0xffu) | ((u64)(wt_flood & 0xffu) << 8) | ((u64)(wt_flood_it & 0xffffu) << 16) | ((u64)(xcc & 0xfu) << 32);
+    }
+#endif
     }   // steps
 }
