@@ -1,23 +1,35 @@
 #!/bin/bash
-# usage (GPU box): bash tools/profile_round.sh r01   -> gpurun_out/prof_<tag>/...
-# kernel-trace stats of the default bench command, then HBM traffic counters in separate
-# --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md).
-tag=${1:-r01}
+# usage (GPU box): bash tools/profile_round.sh r02   -> gpurun_out/prof_<tag>/...
+# rocprofv3 kernel-trace stats and HBM traffic counters (separate --pmc passes: FETCH_SIZE and WRITE_SIZE do not
+# fit one pass; MI355X_MICROARCH.md) for
+#   c3     65 536 x 14x14 (headline; default two-launch step, and one launch per step)
+#   c4     1 024 x 256x256, 1 % pre-ignited, no-op (wf_step_tiled + wf_big_*; 268 MB of state: past the 256 MB Infinity Cache)
+#   hbm    1 048 576 x 14x14 (wf_step_rows on 822 MB of state: true HBM streaming)
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
-# one launch per step (no two-stream split): per-kernel durations that do not overlap each other
-WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_single -- python3 bench.py --no-extras --no-cpu-baseline > $out/bench_single_under_rocprof.log 2>&1
-# counters are collected with one launch per step too (kernels serialise under --pmc anyway)
+B="python3 bench.py --no-extras --no-cpu-baseline"
+C4="--size 256 --batch 1024 --noop --ignite-ppm 10000 --steps 200 --warmup 20"
+HB="--batch 1048576 --steps 120 --warmup 20"
+PM="--steps 40 --warmup 400"
+# ---- kernel-trace stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c3 -- python3 bench.py --no-cpu-baseline > $out/kt_c3.log 2>&1
+WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c3_single -- $B > $out/kt_c3_single.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c4 -- $B $C4 > $out/kt_c4.log 2>&1
+WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c4_single -- $B $C4 > $out/kt_c4_single.log 2>&1
+WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_hbm_single -- $B $HB > $out/kt_hbm_single.log 2>&1
+# ---- counters (one launch per step: kernels serialise under --pmc anyway)
 export WF_NO_SPLIT=1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 40 --warmup 400 --no-extras --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 40 --warmup 400 --no-extras --no-cpu-baseline > $out/pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2 -- python3 bench.py --steps 40 --warmup 400 --no-extras --no-cpu-baseline > $out/pmc_l2.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_insts -- python3 bench.py --steps 40 --warmup 400 --no-extras --no-cpu-baseline > $out/pmc_insts.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_c3_$c -- $B $PM > $out/pmc_c3_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_c4_$c -- $B $C4 --steps 60 --warmup 60 > $out/pmc_c4_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_hbm_$c -- $B $HB --steps 40 --warmup 60 > $out/pmc_hbm_$c.log 2>&1
+done
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_c3_l2 -- $B $PM > $out/pmc_c3_l2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_c3_insts -- $B $PM > $out/pmc_c3_insts.log 2>&1
 unset WF_NO_SPLIT
-# the same bench un-profiled, for the agreement check
+# ---- the same bench un-profiled, for the agreement check
 python3 bench.py > $out/bench_plain.json 2> $out/bench_plain.err
-find $out/kt -name "*kernel_stats.csv" | head -1 | xargs cat
-find $out/kt_single -name "*kernel_stats.csv" | head -1 | xargs cat
-for d in pmc_fetch pmc_write pmc_l2 pmc_insts; do python tools/pmc_summary.py $out/$d | grep -A10 "wf_step_"; done
-tail -1 $out/bench_plain.json
+for d in kt_c3 kt_c3_single kt_c4 kt_c4_single kt_hbm_single; do echo "== $d"; find $out/$d -name "*kernel_stats.csv" | head -1 | xargs cat | grep -E "Name|wf_"; done
+for d in $out/pmc_*; do [ -d $d ] && { echo "== $d"; python tools/pmc_summary.py $d 1 | grep -A12 "wf_"; }; done
+tail -c 600 $out/bench_plain.json
