@@ -116,8 +116,8 @@ def test_big_grid_step_matches_oracle(wf, W, H, B):
         np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
         np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
         np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
-        if t % 10 == 0:
-            np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        # World.get_state(): written by the tiled step kernel itself when H % 4 == 0, else by the observation kernel
+        np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
     env.close()
 
 

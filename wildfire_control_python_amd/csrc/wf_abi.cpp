@@ -537,12 +537,15 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.done = d_done ? d_done + off + lo : nullptr;
             a.n_steps = 1;
             a.update_mask = (update_mask >> st) & 1ull;
+            // World.get_state() of the final state: written by the tiled step kernel itself where the shape allows,
+            // else by the observation kernel behind it - on the share's own stream either way (no join for it)
+            const bool want_obs = d_obs && st == n_steps - 1;
+            const bool fused_obs = want_obs && c->fam == WF_FAM_TILED && wf_tiled_fused_obs(c->H, c->W);
+            a.obs = fused_obs ? d_obs + (size_t)lo * cells * 3 : nullptr;
             u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H) * 8 : nullptr;
             hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
             HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, halo, c->p.seed, si));
-            // World.get_state() of the final state: every share writes its own environments on its own stream
-            // (no join of the shares for it)
-            if (d_obs && st == n_steps - 1)
+            if (want_obs && !fused_obs)
                 HIP_TRY(c, wf_launch_get_state(a.planes_out, d_obs + (size_t)lo * cells * 3, hi - lo, c->H, c->W, si));
         }
         if (c->planes_alt) { uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t; }   // ping-pong

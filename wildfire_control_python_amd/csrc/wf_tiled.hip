@@ -191,10 +191,49 @@ struct TiledAcc { uint32_t anyfire, bhit, healthy, reach_hit; u64 ign_x0, ign_xl
 struct TiledDst { __amdgpu_buffer_rsrc_t rsrc; uint32_t lane_off; };
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 
-template <bool STEP, bool REACH>
+// Fused observation (World.get_state, environment.py:399-402) of the tiled family.  obs[b][x][y][k] is transposed
+// against the planes' [y][x] and has 3 bytes per cell, so a workgroup stages the byte triples (agent_pos, type == fire,
+// fire_mobility != inf) of its 64 rows row-major in LDS - 12 contiguous bytes per lane and row, conflict-free dword
+// writes - and, once its four strips are done, thread x walks down column x: four rows' triples are four unaligned LDS
+// dword reads, packed into the 12 contiguous bytes obs[x][4g..4g+3][0..2].  Needs H % 4 == 0 (4-byte aligned runs).
+struct ObsTile { uint8_t *base; uint32_t W3, row0; };        // LDS tile [64][W*3] (+4 bytes), first row of the workgroup
+
+__device__ __forceinline__ void stage_obs_row(const ObsTile &ot, uint32_t r, uint32_t lane, const uint32_t (&c)[4])
+{
+    uint32_t tri[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t t = c[j] & 0xffu;
+        tri[j] = (c[j] >> 24) | (t == (uint32_t)WF_FIRE ? 0x100u : 0u) | (t < (uint32_t)WF_DIRT ? 0x10000u : 0u);
+    }
+    uint32_t *p = reinterpret_cast<uint32_t *>(ot.base + (r - ot.row0) * ot.W3 + lane * 12u);
+    p[0] = tri[0] | (tri[1] << 24);
+    p[1] = (tri[1] >> 8) | (tri[2] << 16);
+    p[2] = (tri[2] >> 16) | (tri[3] << 8);
+}
+
+// rows [row0, row0 + nrows) of the tile -> obs_e (this environment's (W, H, 3) block); nrows % 4 == 0
+__device__ __forceinline__ void flush_obs_tile(const ObsTile &ot, uint32_t nrows, uint32_t W, uint32_t H, int8_t *obs_e)
+{
+    const uint32_t x = threadIdx.x;
+    if (x >= W) return;
+    struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+    for (uint32_t g = 0; g < nrows; g += 4u) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_memcpy(&v[k], ot.base + (g + (uint32_t)k) * ot.W3 + x * 3u, 4);      // unaligned LDS dword read
+            v[k] &= 0xffffffu;
+        }
+        *reinterpret_cast<U3 *>(obs_e + ((size_t)x * H + ot.row0 + g) * 3u) =
+            U3{ v[0] | (v[1] << 24), (v[1] >> 8) | (v[2] << 16), (v[2] >> 16) | (v[3] << 8) };
+    }
+}
+
+template <bool STEP, bool REACH, bool OBS>
 __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, uint32_t ign, bool active, const uint4 &cur,
                                           const u64 (&Sp)[4], const u64 (&Sc)[4], const u64 (&Sn)[4], const u64 *reach_e,
-                                          const TiledDst &dst, TiledAcc &A)
+                                          const TiledDst &dst, const ObsTile &ot, TiledAcc &A)
 {
     uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
     u64 FIRE[4], GR[4];
@@ -239,15 +278,18 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
     }
     A.anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
     A.healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
+    if constexpr (OBS) {
+        if (active) stage_obs_row(ot, r, __lane_id(), c);
+    }
     if constexpr (STEP) {
         if (active && ((c[0] ^ cur.x) | (c[1] ^ cur.y) | (c[2] ^ cur.z) | (c[3] ^ cur.w)))
             __builtin_amdgcn_raw_buffer_store_b128(v4u32{ c[0], c[1], c[2], c[3] }, dst.rsrc, (int)(dst.lane_off + r * LW * 16u), 0, WF_TILED_STORE_AUX);
     }
 }
 
-template <bool STEP, bool REACH>
+template <bool STEP, bool REACH, bool OBS>
 __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, bool active,
-                                            const uint4 *src, const TiledDst &dst, const uint4 &first, const u64 (&Sf)[4],
+                                            const uint4 *src, const TiledDst &dst, const ObsTile &ot, const uint4 &first, const u64 (&Sf)[4],
                                             const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, TiledAcc &A)
 {
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
@@ -270,7 +312,7 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Sn[j] = Sbelow[j];
                 }
-                tiled_row<STEP, REACH>(rr, H, LW, ign, active, C[k], M[kp], M[k], Sn, reach_e, dst, A);
+                tiled_row<STEP, REACH, OBS>(rr, H, LW, ign, active, C[k], M[kp], M[k], Sn, reach_e, dst, ot, A);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) M[kn][j] = Sn[j];
             }
@@ -278,9 +320,11 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
     }
 }
 
+template <bool OBS>
 __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer)
 {
     __shared__ u64 halo[4][2][4];                    // [strip][first,last row][component]
+    extern __shared__ __attribute__((aligned(16))) uint8_t obs_lds[];     // OBS: [64][W*3] (+4) staging tile
     const uint32_t lane = __lane_id();
     const uint32_t wv = rfl(threadIdx.x >> 6);
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
@@ -292,7 +336,24 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const bool active = lane < LW;
     const uint32_t ign = (uint32_t)a.ignite_count;
     const uint32_t md = mode[e];
-    if ((md & MODE_MASK) != MODE_STEP) return;             // frozen / freshly reset environment: nothing to do
+    const uint32_t wg_row0 = (blockIdx.x % gx) * 4u * TR;
+    const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
+    int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
+    if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
+        if constexpr (OBS) {                               // ... but its observation is still due
+            if (has_rows && active) {
+                const uint4 *srcq = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+                for (uint32_t r = r0; r < r1; ++r) {
+                    const uint4 q = srcq[r * LW];
+                    const uint32_t cq[4] = { q.x, q.y, q.z, q.w };
+                    stage_obs_row(ot, r, lane, cq);
+                }
+            }
+            __syncthreads();
+            flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
+        }
+        return;
+    }
     const bool step = (a.update_mask & 1ull) != 0;
     const bool reach_test = (md & MODE_PRECHECK) != 0;
     const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4] in this kernel's mask layout
@@ -317,7 +378,13 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
         for (int j = 0; j < 4; ++j) { halo[wv][0][j] = Sf[j]; halo[wv][1][j] = Sl[j]; }
     }
     __syncthreads();
-    if (!has_rows) return;
+    if (!has_rows) {
+        if constexpr (OBS) {                               // (no rows of its own, but it is one of the flushing threads)
+            __syncthreads();
+            flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
+        }
+        return;
+    }
 
     // masks of the row above the strip / below the strip (original state): neighbour strip through LDS,
     // neighbour workgroup from the saved outer halos
@@ -340,17 +407,21 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     // ---- sweep
     TiledAcc A = { 0, 0, 0, 0, 0, 0 };
     if (step) {
-        if (reach_test) tiled_sweep<true, true>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
-        else tiled_sweep<true, false>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
+        if (reach_test) tiled_sweep<true, true, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        else tiled_sweep<true, false, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
     } else {
-        if (reach_test) tiled_sweep<false, true>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
-        else tiled_sweep<false, false>(r0, r1, H, LW, ign, active, src, dst, first, Sf, Sp, Sb, reach_e, A);
+        if (reach_test) tiled_sweep<false, true, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        else tiled_sweep<false, false, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
     }
     A.bhit |= ((A.ign_x0 & 1ull) | (A.ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
     if (lane == 0) {
         const uint32_t R = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
         if (R) atomicOr(&acc[2 * e], R);
         if (A.healthy) atomicAdd(&acc[2 * e + 1], A.healthy);
+    }
+    if constexpr (OBS) {
+        __syncthreads();
+        flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
     }
 }
 
@@ -569,53 +640,69 @@ __global__ __launch_bounds__(256) void wf_big_reset_rec(const WfArgs a, const ui
     reset_record(a, e, seed);
 }
 
+// Tasks = (environment, chunk of WF_RESET_CHUNK cells), spread over the workgroups of a bounded grid.  (One workgroup
+// per environment made a 256x256 reset a 100 us serial job of 256 threads; with finished environments being reset
+// every step of a long 1 024 x 256x256 run that was a quarter of the step time.)  Environments that are not being
+// reset cost their tasks one byte load each.
+constexpr uint32_t WF_RESET_CHUNK = 8192;
+
 __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const uint8_t *sel, int sel_value, u64 seed)
 {
-    // one workgroup per environment: environments that are not being reset cost one load
-    const uint32_t e = blockIdx.x;
-    if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) return;
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
-    const WfCold *cold = a.cold;
-    const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
-    const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1), ppm = cold->p.ignite_ppm;
-    const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec
-    const EnvKey key(seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
-    const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
-    uint32_t *pe = a.planes + (size_t)e * cells;
-    bool border_fire = false;
-    // reset_map's river (environment.py:69-95): column of the water cell of every row (0xffff: none), walked once
+    const uint32_t chunks = (cells + WF_RESET_CHUNK - 1u) / WF_RESET_CHUNK, ntasks = (uint32_t)a.batch * chunks;
+    // reset_map's river (environment.py:69-95): column of the water cell of every row (0xffff: none)
     __shared__ uint16_t river_x[WF_RIVER_MAX_H];
-    const bool rivers = cold->p.make_rivers != 0;
-    if (rivers) {
-        for (uint32_t r = threadIdx.x; r < H; r += 256u) river_x[r] = 0xffffu;
-        __syncthreads();
-        if (threadIdx.x == 0) river_cells(key, (int)W, (int)H, [&](int x, int y) { river_x[y] = (uint16_t)x; });
-        __syncthreads();
-    }
-    for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
-        uint32_t fuel = (uint32_t)fuel_lo;
-        if (span > 1u) fuel += below(key.draw(16u + q), span);
-        uint32_t ty = WF_GRASS, heat = 0, ag = 0;
-        if (rivers && river_x[q / W] == q % W) ty = WF_WATER;
-        if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
-        if (q == qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
-        if (ppm && ty == WF_GRASS && below(key.draw(16u + cells + q), 1000000u) < ppm) {
-            ty = WF_FIRE;
-            heat = WF_HEAT_FORCED;
-            const uint32_t x = q % W, y = q / W;
-            border_fire |= (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+    const WfCold *cold = a.cold;
+    for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const uint32_t e = task / chunks, q0 = (task % chunks) * WF_RESET_CHUNK, q1 = min(q0 + WF_RESET_CHUNK, cells);
+        if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) continue;
+        const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
+        const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1), ppm = cold->p.ignite_ppm;
+        const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec / wf_big_pre
+        const EnvKey key(seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
+        const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
+        uint32_t *pe = a.planes + (size_t)e * cells;
+        bool border_fire = false;
+        const bool rivers = cold->p.make_rivers != 0;
+        if (rivers) {                                                      // (every chunk walks the river: it is short)
+            __syncthreads();
+            for (uint32_t r = threadIdx.x; r < H; r += 256u) river_x[r] = 0xffffu;
+            __syncthreads();
+            if (threadIdx.x == 0) river_cells(key, (int)W, (int)H, [&](int x, int y) { river_x[y] = (uint16_t)x; });
+            __syncthreads();
         }
-        pe[q] = ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
+        for (uint32_t q = q0 + threadIdx.x; q < q1; q += 256u) {
+            uint32_t fuel = (uint32_t)fuel_lo;
+            if (span > 1u) fuel += below(key.draw(16u + q), span);
+            uint32_t ty = WF_GRASS, heat = 0, ag = 0;
+            if (rivers && river_x[q / W] == q % W) ty = WF_WATER;
+            if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
+            if (q == qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
+            if (ppm && ty == WF_GRASS && below(key.draw(16u + cells + q), 1000000u) < ppm) {
+                ty = WF_FIRE;
+                heat = WF_HEAT_FORCED;
+                const uint32_t x = q % W, y = q / W;
+                border_fire |= (x == 0 || y == 0 || x == W - 1 || y == H - 1);
+            }
+            pe[q] = ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
+        }
+        if (__ballot(border_fire) && __lane_id() == 0)
+            atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
     }
-    if (__ballot(border_fire) && __lane_id() == 0)
-        atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
 }
 
 }  // namespace
 
+static unsigned reset_cells_grid(const WfArgs &a)
+{
+    const unsigned long long chunks = ((unsigned long long)a.H * a.W + WF_RESET_CHUNK - 1) / WF_RESET_CHUNK;
+    const unsigned long long tasks = chunks * (unsigned long long)a.batch;
+    return (unsigned)(tasks < 4096 ? tasks : 4096);
+}
+
 static hipError_t launch_reset_cells(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s)
 {
-    hipLaunchKernelGGL(wf_big_reset_cells, dim3((unsigned)a.batch), dim3(256), 0, s, a, sel, sel_value, seed);
+    hipLaunchKernelGGL(wf_big_reset_cells, dim3(reset_cells_grid(a)), dim3(256), 0, s, a, sel, sel_value, seed);
     return hipGetLastError();
 }
 
@@ -623,11 +710,13 @@ hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_valu
 {
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_reset_rec, dim3(eb), dim3(256), 0, s, a, sel, sel_value, seed);
-    hipLaunchKernelGGL(wf_big_reset_cells, dim3((unsigned)a.batch), dim3(256), 0, s, a, sel, sel_value, seed);
-    return hipGetLastError();
+    return launch_reset_cells(a, sel, sel_value, seed, s);
 }
 
 int wf_tiled_groups(int H) { return (H + 4 * TR - 1) / (4 * TR); }
+
+// wf_step_tiled can write the observation itself when the (x, y-run) blocks of obs are 4-byte aligned
+bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s)
 {
@@ -651,7 +740,10 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
             const unsigned tasks = (unsigned)a.batch * gx * 2u;
             hipLaunchKernelGGL(wf_big_halo, dim3((tasks + 3) / 4), dim3(256), 0, s, a, (const uint8_t *)mode, halo);
         }
-        hipLaunchKernelGGL(wf_step_tiled, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc, (const u64 *)halo);
+        if (a.obs)      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
+            hipLaunchKernelGGL(wf_step_tiled<true>, dim3(gx * (unsigned)a.batch), dim3(256), (size_t)(4 * TR) * a.W * 3 + 16, s, a, mode, acc, (const u64 *)halo);
+        else
+            hipLaunchKernelGGL(wf_step_tiled<false>, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc, (const u64 *)halo);
     } else {
         const size_t total = (size_t)a.batch * a.H * a.W;
         size_t blocks = (total + 255) / 256;
