@@ -22,12 +22,14 @@ WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_hb
 export WF_NO_SPLIT=1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_c3_$c -- $B $PM > $out/pmc_c3_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_c4_$c -- $B $C4 --steps 60 --warmup 60 > $out/pmc_c4_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_hbm_$c -- $B $HB --steps 40 --warmup 60 > $out/pmc_hbm_$c.log 2>&1
+  # (--min-ms 0: exactly ticks 60..120, the regime tools/c4_write_amp.py counts changed quads in)
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_c4_$c -- $B $C4 --steps 60 --warmup 60 --min-ms 0 > $out/pmc_c4_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_hbm_$c -- $B $HB --steps 40 --warmup 60 --min-ms 0 > $out/pmc_hbm_$c.log 2>&1
 done
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_c3_l2 -- $B $PM > $out/pmc_c3_l2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_c3_insts -- $B $PM > $out/pmc_c3_insts.log 2>&1
 unset WF_NO_SPLIT
+python3 tools/c4_write_amp.py > $out/c4_write_amp.json 2> $out/c4_write_amp.err
 # ---- the same bench un-profiled, for the agreement check
 python3 bench.py > $out/bench_plain.json 2> $out/bench_plain.err
 for d in kt_c3 kt_c3_single kt_c4 kt_c4_single kt_hbm_single; do echo "== $d"; find $out/$d -name "*kernel_stats.csv" | head -1 | xargs cat | grep -E "Name|wf_"; done
