@@ -1,60 +1,106 @@
 """Copy the judged summaries of `tools/profile_round.sh <tag>` from gpurun_out/prof_<tag>/ into profiles/.
-usage (here, after the gpurun call): python tools/collect_profiles.py r01"""
-import csv, glob, json, os, re, shutil, subprocess, sys, tempfile
+usage (here, after the gpurun call): python tools/collect_profiles.py r02"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
+
+RUNS = [  # (directory, what was run)
+    ("kt_c3", "python3 bench.py --no-cpu-baseline   (default run, 65 536 x 14x14: a step = 2 concurrent half-batch launches of "
+              "wf_step_rows, so their durations overlap; the calls also hold the extra legs' launches: c2 / c4 / c5_shard / hbm_1m)"),
+    ("kt_c3_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline   (65 536 x 14x14, ONE launch per step: compare "
+                     "AverageNs with roofline.single_launch.launch_us of the bench line)"),
+    ("kt_c4", "python3 bench.py --no-extras --no-cpu-baseline --size 256 --batch 1024 --noop --ignite-ppm 10000 --steps 200 --warmup 20"
+              "   (BASELINE configs[3]; a step = 2 concurrent launch sequences on 2 streams)"),
+    ("kt_c4_single", "WF_NO_SPLIT=1, same command   (BASELINE configs[3], one launch sequence per step: the per-kernel durations add up to the step)"),
+    ("kt_hbm_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline --batch 1048576 --steps 120 --warmup 20"
+                      "   (1 048 576 x 14x14 = 822 MB of state: true HBM streaming, one launch per step)"),
+]
 
 
 def newest(d, pat):
-    return sorted(glob.glob(os.path.join(d, "*", pat)), key=os.path.getmtime)[-1]
+    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)[-1]
 
 
 def rows(f):
     r = list(csv.reader(open(f)))
-    return [r[0]] + [x for x in r[1:] if "wf_" in x[0] or "rocclr" in x[0]]
+    return [r[0]] + [x for x in r[1:] if "wf_" in x[0]]
 
 
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as fo:
     w = csv.writer(fo)
-    fo.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (default run: a step = 2 concurrent "
-             "half-batch launches of wf_step_rows, so their durations overlap; the calls also hold the extra legs' launches)\n")
-    [w.writerow(x) for x in rows(newest(f"{src}/kt", "*_kernel_stats.csv"))]
-    fo.write("# WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras --no-cpu-baseline   (one launch per "
-             "step: compare AverageNs with roofline.single_launch.launch_us of the bench line)\n")
-    [w.writerow(x) for x in rows(newest(f"{src}/kt_single", "*_kernel_stats.csv"))]
+    for d, what in RUNS:
+        fo.write(f"# rocprofv3 --kernel-trace --stats -- {what}\n")
+        [w.writerow(x) for x in rows(newest(f"{src}/{d}", "*_kernel_stats.csv"))]
 
-txt, vals = [], {}
-for d in ["pmc_fetch", "pmc_write", "pmc_l2", "pmc_insts"]:
-    f = newest(f"{src}/{d}", "*_counter_collection.csv")
-    tmp = tempfile.mkdtemp()
-    os.makedirs(tmp + "/runc")
-    shutil.copy(f, tmp + "/runc/")
-    out = subprocess.run([sys.executable, "tools/pmc_summary.py", tmp], capture_output=True, text=True).stdout
-    keep = False
-    for l in out.split("\n"):
-        if l and not l.startswith(" "):
-            keep = "wf_step_rows" in l
-        if keep and l.strip():
-            txt.append(l)
-            m = re.match(r"\s+(\w+)\s+n=\s*(\d+)\s+mean=\s*([\d.]+)", l)
-            if m:
-                vals[m.group(1)] = float(m.group(3))
-open(f"profiles/{tag}_pmc_summary.txt", "w").write(
-    "# separate rocprofv3 --pmc passes of: WF_NO_SPLIT=1 python3 bench.py --steps 40 --warmup 400 --no-extras --no-cpu-baseline\n"
-    "# (one launch per step, steady state; mean over all launches; per_env = mean / 65536; FETCH_SIZE / WRITE_SIZE in KiB)\n"
-    + "\n".join(txt) + "\n")
-fetch, write = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
-t = {"round": int(tag[1:]), "kernel": "wf_step_rows<14,14,2,false>",
-     "workload": "65536 x 14x14, bench.py default (counters collected with one launch per step, steady state)",
-     "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "read_bytes_corrected": fetch,
-     "write_bytes": write, "traffic_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 102760448,
-     "note": "separate --pmc passes (profiles/%s_pmc_summary.txt); FETCH_SIZE doubled per the gfx950 correction; L2<->fabric "
-             "bytes, Infinity-Cache hits included; unchanged row pieces are not written back, so the traffic is below the "
-             "algorithmic 8 B per cell-update" % tag}
+
+def counters(d):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    # (gpurun merges runs into gpurun_out/ without deleting older files: the newest csv of the directory only)
+    for f in sorted(glob.glob(f"{src}/{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+lines, vals = [], {}
+for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
+                        ("c4", "wf_step_tiled", "1 024 x 256x256 (268 MB; WF_NO_SPLIT=1, ticks 60..120 after the reset, --min-ms 0)"),
+                        ("hbm", "wf_step_rows", "1 048 576 x 14x14 (822 MB; WF_NO_SPLIT=1, steps 60..100, --min-ms 0)")):
+    lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
+    for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
+        if not os.path.isdir(d):
+            continue
+        for k, v in counters(os.path.basename(d)).items():
+            if kern not in k and not (cfg == "c4" and "wf_big" in k):
+                continue
+            lines.append(k[:100])
+            for c, xs in sorted(v.items()):
+                m = sum(xs) / len(xs)
+                lines.append(f"    {c:24s} n={len(xs):4d} mean={m:14.1f}")
+                if kern in k:
+                    vals[(cfg, c)] = m
+open(f"profiles/{tag}_pmc_summary.txt", "w").write("\n".join(lines) + "\n")
+
+amp = json.load(open(f"{src}/c4_write_amp.json"))
+shutil.copy(f"{src}/c4_write_amp.json", f"profiles/{tag}_c4_write_amp.json")
+
+
+def traffic(cfg, kernel, cells, workload):
+    fetch_kib, write_kib = vals[(cfg, "FETCH_SIZE")], vals[(cfg, "WRITE_SIZE")]
+    rd, wr = fetch_kib * 1024 * 2, write_kib * 1024
+    return {"kernel": kernel, "workload": workload, "state_bytes": cells * 4, "algorithmic_bytes_per_launch": cells * 8,
+            "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+            "read_bytes_uncorrected": fetch_kib * 1024, "read_bytes_corrected": rd, "write_bytes": wr,
+            "traffic_bytes_per_launch": rd + wr, "read_over_state": rd / (cells * 4), "written_over_state": wr / (cells * 4)}
+
+
+t = traffic("c3", "wf_step_rows<14,14,2,false>", 65536 * 196,
+            "65536 x 14x14, bench.py default (counters collected with one launch per step, steady state)")
+t["round"] = int(tag[1:])
+t["note"] = ("separate --pmc passes (profiles/%s_pmc_summary.txt).  FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md - "
+             "which is documented for 16-B-per-lane streaming loads; these are 28-byte-stride dwordx4 + dwordx3 loads, so the uncorrected "
+             "figure is given too and the truth lies between them.  L2<->fabric bytes, Infinity-Cache hits included (the 51 MB state sits "
+             "in the 256 MB Infinity Cache); unchanged row pieces are not written back, so the traffic is below the algorithmic 8 B per "
+             "cell-update" % tag)
+t["other_sizes"] = {
+    "c4_tiled": traffic("c4", "wf_step_tiled", 1024 * 65536, "1024 x 256x256, 10000 ppm pre-ignited, no-op, ticks 60..120 (268 MB: past the Infinity Cache)"),
+    "hbm_1m": traffic("hbm", "wf_step_rows<14,14,2,false>", 1048576 * 196, "1048576 x 14x14, bench inputs (822 MB: true HBM streaming)"),
+}
+c4 = t["other_sizes"]["c4_tiled"]
+c4["changed_quad_bytes_per_tick"] = amp["mean_changed_quad_bytes"]
+c4["changed_128B_line_bytes_per_tick"] = amp["mean_changed_line_bytes"]
+c4["dirty_line_write_amplification"] = c4["write_bytes"] / amp["mean_changed_quad_bytes"]
+c4["note"] = ("a lane stores its 16-byte quad only if one of its four cells changed (tools/c4_write_amp.py counts them on the host in the "
+              "same tick window); WRITE_SIZE / changed-quad bytes = write amplification of whole dirty lines leaving L2")
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 shutil.copy(f"{src}/bench_plain.json", f"profiles/{tag}_bench_plain.json")
-print(open(f"profiles/{tag}_kernel_stats.csv").read())
+print(open(f"profiles/{tag}_kernel_stats.csv").read()[:6000])
 print(open(f"profiles/{tag}_pmc_summary.txt").read())
 print(json.dumps(t, indent=1))
-print(open(f"profiles/{tag}_bench_plain.json").read()[-1500:])
