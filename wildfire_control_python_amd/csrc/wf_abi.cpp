@@ -306,9 +306,9 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
                 if ((e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
             }
             if ((e = hipMalloc((void **)&c->d_mode, (size_t)batch)) != hipSuccess) break;
-            if ((e = hipMalloc((void **)&c->d_acc, (size_t)batch * 8)) != hipSuccess) break;
+            if ((e = hipMalloc((void **)&c->d_acc, (size_t)batch * 16)) != hipSuccess) break;   // 4 words per environment
             if ((e = hipMemsetAsync(c->d_mode, 0, (size_t)batch, c->stream)) != hipSuccess) break;
-            if ((e = hipMemsetAsync(c->d_acc, 0, (size_t)batch * 8, c->stream)) != hipSuccess) break;
+            if ((e = hipMemsetAsync(c->d_acc, 0, (size_t)batch * 16, c->stream)) != hipSuccess) break;
         }
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
         // wave family: (batch,4) boards of the 4-cells-per-lane kernels + as much again for the rows layout
@@ -544,7 +544,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.obs = fused_obs ? d_obs + (size_t)lo * cells * 3 : nullptr;
             u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H) * 8 : nullptr;
             hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
-            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 2, halo, c->p.seed, si));
+            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 4, halo, c->p.seed, si));
             if (want_obs && !fused_obs)
                 HIP_TRY(c, wf_launch_get_state(a.planes_out, d_obs + (size_t)lo * cells * 3, hi - lo, c->H, c->W, si));
         }

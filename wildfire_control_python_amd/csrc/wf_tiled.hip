@@ -1,13 +1,17 @@
 // wf_tiled.hip - gfx950 kernels for grids that do not fit one wavefront (e.g. 256x256).
 //
 // Same rule as wf_kernels.hip (synchronous integer restatement of
-// Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step is
-//   wf_big_pre   lanes = environments: Agent.move / toggle / death (environment.py:116-171);
-//                the dug cell and the agent_pos bytes are written straight into the grid
-//   wf_step_tiled (W % 4 == 0, W <= 256)  or  wf_step_cells (any shape)
-//                the CA tick, source planes -> destination planes (ping-pong), per-env
-//                reductions (any fire left, fire at border, healthy cells) by atomics
-//   wf_big_post  lanes = environments: World.RUNNING, reward, done, records
+// Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step of the TILED family
+// (W % 4 == 0, W <= 256) is at most three launches:
+//   wf_tiled_prologue   one workgroup per environment: Agent.move / toggle / death (environment.py:116-171) with
+//                       the dug cell and the agent_pos bytes written straight into the grid; the border-reachability
+//                       flood when a dig may have cut a region off; the still-burning masks of the rows between the
+//                       workgroups of the tick (it runs in place)
+//   wf_big_reset_cells  auto-reset only: World.reset() of the environments that were finished
+//   wf_step_tiled       the CA tick in place (+ the observation, when asked for); per-env reductions by atomics, and the
+//                       last of an environment's workgroups to arrive does World.RUNNING, reward, done, record
+// and of the GENERIC family (any shape, thread per cell, ping-pong planes):
+//   wf_big_pre -> [wf_big_reset_cells] -> [wf_cells_flood] -> wf_step_cells -> wf_big_post
 //
 // wf_step_tiled: a workgroup = 4 waves = 4 vertically adjacent strips of TR rows of one
 // environment.  A wave sweeps its strip top to bottom; lane l owns cells x = 4l..4l+3 of
@@ -47,20 +51,20 @@ __device__ __forceinline__ void reset_record(const WfArgs &a, uint32_t e, u64 se
 }
 
 // ---------------------------------------------------------------------------- pre
-__global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
+// Agent.move / toggle / death and the containment bookkeeping of ONE environment (run by one lane): applies the touched
+// bytes to the grid, returns the step mode; the updated record is left in `ev` for the caller to write.
+__device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t e, uint4 &ev, bool &have_record)
 {
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    if (e >= (uint32_t)a.batch) return;
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H;
-    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    have_record = false;
     uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu;
     if (!(fl & WF_F_RUNNING)) {
         const bool rs = (a.hot_flags & WF_HOT_AUTO_RESET) != 0;
-        mode[e] = rs ? MODE_RESET : MODE_COPY;     // frozen: the reference is never stepped after done
         if (a.reward) a.reward[e] = 0.0;
         if (a.done) a.done[e] = rs ? 0 : 1;
         if (rs) reset_record(a, e, a.cold->p.seed);   // the cells follow in wf_big_reset_cells
-        return;
+        return rs ? MODE_RESET : MODE_COPY;           // frozen: the reference is never stepped after done
     }
     const uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[e] : 0xffu;
     uint8_t *pe = reinterpret_cast<uint8_t *>(a.planes) + (size_t)e * H * W * 4;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
         if (dies) fl &= ~(uint32_t)(WF_F_ALIVE | WF_F_VISIBLE);
     }
     // containment bookkeeping (same exact rule as wf_step_group's phase A): can this dig change
-    // which cells reach the border?  If so the board is rebuilt by wf_big_flood before the tick.
+    // which cells reach the border?  If so the board is rebuilt (wf_tiled_prologue / wf_cells_flood) before the tick.
     uint32_t m = MODE_STEP;
     if ((a.hot_flags & WF_HOT_CONTAINMENT) && !(fl & (WF_F_BORDER | WF_F_CONTAINED))) {
         m |= MODE_PRECHECK;
@@ -120,25 +124,31 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
         }
         if (flood) m |= MODE_FLOOD;
     }
-    mode[e] = (uint8_t)m;
     if (vis_before) pe[(size_t)qa * 4 + 3] = 0;
     if (dug) pe[(size_t)qd * 4] = (uint8_t)dugtype;
     if (fl & WF_F_VISIBLE) pe[(size_t)(ay * W + ax) * 4 + 3] = 1;
     ev.x = ax | (ay << 16);
     ev.y = fl;
-    *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+    have_record = true;                               // the caller writes it (after a flood, with its valid flag)
+    return m;
 }
 
-// ---------------------------------------------------------------------------- post
-__global__ __launch_bounds__(256) void wf_big_post(const WfArgs a, const uint8_t *mode, uint32_t *acc)
+// generic family: lanes = environments
+__global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
 {
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (uint32_t)a.batch) return;
-    const uint32_t A = acc[2 * e], healthy = acc[2 * e + 1];
-    acc[2 * e] = 0;
-    acc[2 * e + 1] = 0;
-    const uint32_t m = mode[e];
-    if ((m & MODE_MASK) != MODE_STEP) return;
+    uint4 ev;
+    bool have_record;
+    mode[e] = (uint8_t)big_pre_env(a, e, ev, have_record);
+    if (have_record) *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+}
+
+// ---------------------------------------------------------------------------- post
+// World.RUNNING, reward, done and the record of ONE stepped environment from its reduction words
+// (A: bit 0 any fire left, bit 1 fire at the border, bit 2 fire on a border-connected cell; healthy: grass cells).
+__device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, const uint32_t m, const uint32_t A, const uint32_t healthy)
+{
     uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
     uint32_t fl = ev.y & 0xffffu;
     const uint32_t anyfire = A & 1u, bhit = (A >> 1) & 1u, reach_hit = (A >> 2) & 1u;
@@ -160,6 +170,19 @@ __global__ __launch_bounds__(256) void wf_big_post(const WfArgs a, const uint8_t
     if (a.done) a.done[e] = (fl & WF_F_RUNNING) ? 0 : 1;                               // forest_fire.py:48
 }
 
+// generic family: lanes = environments, after the step kernel.  acc: 4 words per environment (flags, healthy, arrivals, -)
+__global__ __launch_bounds__(256) void wf_big_post(const WfArgs a, const uint8_t *mode, uint32_t *acc)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (uint32_t)a.batch) return;
+    const uint32_t A = acc[4 * e], healthy = acc[4 * e + 1];
+    acc[4 * e] = 0;
+    acc[4 * e + 1] = 0;
+    const uint32_t m = mode[e];
+    if ((m & MODE_MASK) != MODE_STEP) return;
+    big_post_env(a, e, m, A, healthy);
+}
+
 // ---------------------------------------------------------------------------- tiled step
 struct RowMasks { u64 m[4]; };
 
@@ -172,7 +195,7 @@ __device__ __forceinline__ void still_masks(const uint4 &r, u64 (&S)[4])
 }
 
 // The step runs IN PLACE (planes_out == planes).  The masks of the two rows just outside the workgroup - which
-// another workgroup may already have rewritten - come from `outer` (wf_big_halo, written before this launch);
+// another workgroup may already have rewritten - come from `outer` (wf_tiled_prologue, written before this launch);
 // environments that are not stepped are not touched at all; a lane stores its four cells only when one of them
 // changed (most cells do not change in a tick).
 //
@@ -378,13 +401,8 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
         for (int j = 0; j < 4; ++j) { halo[wv][0][j] = Sf[j]; halo[wv][1][j] = Sl[j]; }
     }
     __syncthreads();
-    if (!has_rows) {
-        if constexpr (OBS) {                               // (no rows of its own, but it is one of the flushing threads)
-            __syncthreads();
-            flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
-        }
-        return;
-    }
+    TiledAcc A = { 0, 0, 0, 0, 0, 0 };
+    if (has_rows) {                                        // (a wave without rows of its own still flushes and arrives below)
 
     // masks of the row above the strip / below the strip (original state): neighbour strip through LDS,
     // neighbour workgroup from the saved outer halos
@@ -405,7 +423,6 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     }
 
     // ---- sweep
-    TiledAcc A = { 0, 0, 0, 0, 0, 0 };
     if (step) {
         if (reach_test) tiled_sweep<true, true, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
         else tiled_sweep<true, false, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
@@ -415,118 +432,141 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     }
     A.bhit |= ((A.ign_x0 & 1ull) | (A.ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
     if (lane == 0) {
+        // device-scope atomics are performed at the memory side (the per-XCD L2s are not coherent with each other);
+        // the RETURNING forms, consumed, make the wave wait until they have been
         const uint32_t R = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
-        if (R) atomicOr(&acc[2 * e], R);
-        if (A.healthy) atomicAdd(&acc[2 * e + 1], A.healthy);
+        uint32_t o0 = 0, o1 = 0;
+        if (R) o0 = atomicOr(&acc[4 * e], R);
+        if (A.healthy) o1 = atomicAdd(&acc[4 * e + 1], A.healthy);
+        asm volatile("" :: "v"(o0), "v"(o1));
     }
-    if constexpr (OBS) {
-        __syncthreads();
-        flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
-    }
-}
-
-// ---------------------------------------------------------------------------- outer halos (in-place mode)
-// Still-burning masks of the two rows just outside every workgroup of wf_step_tiled, taken from the state
-// BEFORE the tick: halo[(e*gx + g)*8 + 0..3] = row above workgroup g, +4..7 = row below.  One wave per row.
-__global__ __launch_bounds__(256) void wf_big_halo(const WfArgs a, const uint8_t *mode, u64 *halo)
-{
-    const uint32_t lane = __lane_id();
-    const uint32_t H = (uint32_t)a.H, LW = (uint32_t)a.W >> 2;
-    const uint32_t gx = (H + 4u * TR - 1u) / (4u * TR);
-    const uint32_t task = rfl(blockIdx.x * 4u + (threadIdx.x >> 6));      // (e, g, side)
-    if (task >= (uint32_t)a.batch * gx * 2u) return;
-    const uint32_t side = task & 1u, g = (task >> 1) % gx, e = (task >> 1) / gx;
-    if ((mode[e] & MODE_MASK) != MODE_STEP) return;
-    const uint32_t first = g * 4u * TR, endr = min(first + 4u * TR, H);
-    if (side == 0 ? first == 0 : endr >= H) return;                        // grid edge: no such row
-    const uint32_t r = side == 0 ? first - 1u : endr;
-    uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
-    if (lane < LW) c = (reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane)[r * LW];
-    u64 S[4];
-    still_masks(c, S);
-    if (lane == 0) {
-        u64 *o = halo + ((size_t)e * gx + g) * 8 + side * 4u;
-        o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
-    }
-}
-
-// ---------------------------------------------------------------------------- flood
-// Border-reachability board of one environment (tiled family): bit l of word [r][j] = cell
-// (row r, x = 4l+j) is 4-connected to a passable border cell through passable cells.  One
-// workgroup per environment, boards resident in LDS, monotone in-place relaxation until
-// nothing changes.  Environments not flagged MODE_FLOOD cost one load.
-__global__ __launch_bounds__(256) void wf_big_flood(const WfArgs a, const uint8_t *mode)
-{
-    extern __shared__ u64 lds[];                     // [H*4] pass, [H*4] reach
-    __shared__ uint32_t changed;
-    const uint32_t e = blockIdx.x;
-    if (!(mode[e] & MODE_FLOOD)) return;
-    const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2, words = H * 4u;
-    u64 *pass = lds, *reach = lds + words;
-    const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
-    // passable masks, one row per wave iteration
-    for (uint32_t r = wv; r < H; r += 4u) {
-        uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
-        if (lane < LW) c = src[r * LW];
-        const u64 p0 = __ballot((c.x & 0xffu) < WF_DIRT), p1 = __ballot((c.y & 0xffu) < WF_DIRT);
-        const u64 p2 = __ballot((c.z & 0xffu) < WF_DIRT), p3 = __ballot((c.w & 0xffu) < WF_DIRT);
-        if (lane == 0) {
-            const bool edge = r == 0 || r == H - 1;
-            const u64 P[4] = { p0, p1, p2, p3 };
-            for (int j = 0; j < 4; ++j) {
-                pass[r * 4 + j] = P[j];
-                // seeds: passable border cells (first/last row; x == 0 -> word 0 bit 0; x == W-1 -> word 3 bit LW-1)
-                const u64 bm = edge ? ~0ull : (j == 0 ? 1ull : (j == 3 ? (1ull << (LW - 1)) : 0ull));
-                reach[r * 4 + j] = P[j] & bm;
-            }
+    }   // has_rows
+    __syncthreads();
+    if constexpr (OBS) flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
+    // ---- World.RUNNING / reward / done of the environment: by whichever of its gx workgroups arrives last (every wave
+    // of this workgroup has its reduction atomics behind it: the barrier above).  No data but the atomically updated
+    // words passes between the workgroups, so no cache write-back fence is needed.
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(&acc[4 * e + 2], 1u);
+        if (ticket == gx - 1u) {
+            const uint32_t Aw = atomicExch(&acc[4 * e], 0u), healthy = atomicExch(&acc[4 * e + 1], 0u);
+            atomicExch(&acc[4 * e + 2], 0u);
+            big_post_env(a, e, md, Aw, healthy);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------- prologue of a tiled step
+// One workgroup per environment does everything that has to precede the in-place tick, in ONE launch (it used to be
+// three: each kernel boundary of a step costs ~4.5 us that nothing overlaps):
+//   1. thread 0: Agent.move / toggle / death + containment bookkeeping (big_pre_env), touched bytes applied to the grid;
+//   2. if that flagged it: the border-reachability board of the environment is rebuilt (boards resident in LDS,
+//      monotone in-place relaxation until nothing changes): bit l of word [r][j] = cell (row r, x = 4l+j) is
+//      4-connected to a passable border cell through passable cells;
+//   3. the still-burning masks of the two rows just outside every workgroup of wf_step_tiled, taken from the state
+//      BEFORE the tick: halo[(e*gx + g)*8 + 0..3] = row above workgroup g, +4..7 = row below (one wave per row).
+__global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t *mode, u64 *halo)
+{
+    extern __shared__ u64 lds[];                     // flood: [H*4] pass, [H*4] reach
+    __shared__ uint32_t s_mode, changed;
+    const uint32_t e = blockIdx.x;
+    const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2, words = H * 4u;
+    const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
+    uint4 ev;
+    bool have_record = false;
+    if (threadIdx.x == 0) {
+        const uint32_t m = big_pre_env(a, e, ev, have_record);
+        mode[e] = (uint8_t)m;
+        s_mode = m;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the touched bytes, for the other waves of this CU
     }
     __syncthreads();
-    // A relaxation sweep advances the front by at least one cell along every shortest path, and a shortest path
-    // through passable cells has fewer than H*W cells (a serpentine between dirt walls comes close): H*W sweeps
-    // always suffice, like the wave and cell floods; a mere 4*(H+W) would not.
-    bool converged = false;
-    for (uint32_t it = 0; it < H * W; ++it) {
-        if (threadIdx.x == 0) changed = 0;
-        __syncthreads();
-        bool ch = false;
-        for (uint32_t k = threadIdx.x; k < words; k += 256u) {
-            const uint32_t r = k >> 2, j = k & 3u;
-            const u64 cur = reach[k];
-            u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);
-            nb |= j > 0 ? reach[k - 1] : (reach[k + 3] << 1);
-            nb |= j < 3 ? reach[k + 1] : (reach[k - 3] >> 1);
-            const u64 nw = cur | (nb & pass[k]);
-            if (nw != cur) { reach[k] = nw; ch = true; }
-        }
-        if (ch) changed = 1;
-        __syncthreads();
-        if (!changed) { converged = true; break; }
-        __syncthreads();
-    }
-    u64 *out = a.reach + (size_t)e * words;
-    if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
-        // Burning dirt (WF_DIRT_BURNING) is impassable, yet the reference's search starts FROM it: it reaches the
-        // border iff one of its 4-neighbours does.  One row per wave iteration: re-read the row, add those cells.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t md = s_mode;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+    if (md & MODE_FLOOD) {                                           // (only set with the containment test on)
+        u64 *pass = lds, *reach = lds + words;
+        // passable masks, one row per wave iteration
         for (uint32_t r = wv; r < H; r += 4u) {
             uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
             if (lane < LW) c = src[r * LW];
-            const u64 Z[4] = { __ballot((c.x & 0xffu) == WF_DIRT_BURNING), __ballot((c.y & 0xffu) == WF_DIRT_BURNING),
-                               __ballot((c.z & 0xffu) == WF_DIRT_BURNING), __ballot((c.w & 0xffu) == WF_DIRT_BURNING) };
-            if (lane < 4u) {
-                const uint32_t j = lane, k = r * 4u + j;
+            const u64 p0 = __ballot((c.x & 0xffu) < WF_DIRT), p1 = __ballot((c.y & 0xffu) < WF_DIRT);
+            const u64 p2 = __ballot((c.z & 0xffu) < WF_DIRT), p3 = __ballot((c.w & 0xffu) < WF_DIRT);
+            if (lane == 0) {
+                const bool edge = r == 0 || r == H - 1;
+                const u64 P[4] = { p0, p1, p2, p3 };
+                for (int j = 0; j < 4; ++j) {
+                    pass[r * 4 + j] = P[j];
+                    // seeds: passable border cells (first/last row; x == 0 -> word 0 bit 0; x == W-1 -> word 3 bit LW-1)
+                    const u64 bm = edge ? ~0ull : (j == 0 ? 1ull : (j == 3 ? (1ull << (LW - 1)) : 0ull));
+                    reach[r * 4 + j] = P[j] & bm;
+                }
+            }
+        }
+        __syncthreads();
+        // A relaxation sweep advances the front by at least one cell along every shortest path, and a shortest path
+        // through passable cells has fewer than H*W cells (a serpentine between dirt walls comes close): H*W sweeps
+        // always suffice, like the wave and cell floods; a mere 4*(H+W) would not.
+        bool converged = false;
+        for (uint32_t it = 0; it < H * W; ++it) {
+            if (threadIdx.x == 0) changed = 0;
+            __syncthreads();
+            bool ch = false;
+            for (uint32_t k = threadIdx.x; k < words; k += 256u) {
+                const uint32_t r = k >> 2, j = k & 3u;
+                const u64 cur = reach[k];
                 u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);
                 nb |= j > 0 ? reach[k - 1] : (reach[k + 3] << 1);
                 nb |= j < 3 ? reach[k + 1] : (reach[k - 3] >> 1);
-                out[k] = reach[k] | (nb & Z[j]);
+                const u64 nw = cur | (nb & pass[k]);
+                if (nw != cur) { reach[k] = nw; ch = true; }
             }
+            if (ch) changed = 1;
+            __syncthreads();
+            if (!changed) { converged = true; break; }
+            __syncthreads();
         }
-    } else {
-        for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = reach[k];
+        u64 *out = a.reach + (size_t)e * words;
+        if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
+            // Burning dirt (WF_DIRT_BURNING) is impassable, yet the reference's search starts FROM it: it reaches the
+            // border iff one of its 4-neighbours does.  One row per wave iteration: re-read the row, add those cells.
+            for (uint32_t r = wv; r < H; r += 4u) {
+                uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+                if (lane < LW) c = src[r * LW];
+                const u64 Z[4] = { __ballot((c.x & 0xffu) == WF_DIRT_BURNING), __ballot((c.y & 0xffu) == WF_DIRT_BURNING),
+                                   __ballot((c.z & 0xffu) == WF_DIRT_BURNING), __ballot((c.w & 0xffu) == WF_DIRT_BURNING) };
+                if (lane < 4u) {
+                    const uint32_t j = lane, k = r * 4u + j;
+                    u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);
+                    nb |= j > 0 ? reach[k - 1] : (reach[k + 3] << 1);
+                    nb |= j < 3 ? reach[k + 1] : (reach[k - 3] >> 1);
+                    out[k] = reach[k] | (nb & Z[j]);
+                }
+            }
+        } else {
+            for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = reach[k];
+        }
+        // (always true with the H*W bound; a board that did not converge would not be trusted later)
+        if (threadIdx.x == 0 && converged) ev.y |= (uint32_t)WF_F_REACH_VALID;
     }
-    // (never true with the H*W bound; kept so that a board that did not converge could not be trusted later)
-    if (threadIdx.x == 0 && converged) atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_REACH_VALID);
+    if (threadIdx.x == 0 && have_record) *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
+    // ---- outer halos
+    if ((md & MODE_MASK) != MODE_STEP || !halo) return;
+    const uint32_t gx = (H + 4u * TR - 1u) / (4u * TR);
+    for (uint32_t task = wv; task < gx * 2u; task += 4u) {
+        const uint32_t side = task & 1u, g = task >> 1;
+        const uint32_t first = g * 4u * TR, endr = min(first + 4u * TR, H);
+        if (side == 0 ? first == 0 : endr >= H) continue;                  // grid edge: no such row
+        const uint32_t r = side == 0 ? first - 1u : endr;
+        uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+        if (lane < LW) c = src[r * LW];
+        u64 S[4];
+        still_masks(c, S);
+        if (lane == 0) {
+            u64 *o = halo + ((size_t)e * gx + g) * 8 + side * 4u;
+            o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------- flood, generic family
@@ -605,7 +645,7 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
                 const uint32_t room = ign - ((c >> 16) & 0xffu);
                 const uint32_t ig = cnt >= room ? 1u : 0u;                         // apply_heat_from_to :278-294
                 c += (min(cnt, room) << 16) + ig;
-                if (ig && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) atomicOr(&acc[2 * e], 2u);
+                if (ig && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) atomicOr(&acc[4 * e], 2u);
             }
         }
         a.planes_out[(size_t)e * cells + q] = c;
@@ -613,18 +653,18 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
             const uint32_t t = c & 0xffu;
             // containment (environment.py:345-377): a burning cell on a border-connected cell
             if ((mode[e] & MODE_PRECHECK) && (t & 3u) == 1u && reinterpret_cast<const uint8_t *>(a.reach)[(size_t)e * cells + q])
-                atomicOr(&acc[2 * e], 4u);
+                atomicOr(&acc[4 * e], 4u);
             // wave-aggregated when the whole wave sits in one env (the common case)
             const uint32_t e0 = rfl(e);
             if (__ballot(e != e0) == 0) {
                 const u64 f = __ballot((t & 3u) == 1u), g = __ballot(t == WF_GRASS);
                 if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) {
-                    if (f) atomicOr(&acc[2 * e], 1u);
-                    if (g) atomicAdd(&acc[2 * e + 1], (uint32_t)__popcll(g));
+                    if (f) atomicOr(&acc[4 * e], 1u);
+                    if (g) atomicAdd(&acc[4 * e + 1], (uint32_t)__popcll(g));
                 }
             } else {
-                if ((t & 3u) == 1u) atomicOr(&acc[2 * e], 1u);
-                if (t == WF_GRASS) atomicAdd(&acc[2 * e + 1], 1u);
+                if ((t & 3u) == 1u) atomicOr(&acc[4 * e], 1u);
+                if (t == WF_GRASS) atomicAdd(&acc[4 * e + 1], 1u);
             }
         }
     }
@@ -720,36 +760,36 @@ bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s)
 {
+    if (fam == WF_FAM_TILED) {
+        // prologue (agent logic, reachability flood, outer halos) -> [reset of finished environments] -> the in-place
+        // tick, whose last workgroup per environment also does World.RUNNING / reward / done
+        const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
+        const size_t flood_lds = (a.hot_flags & WF_HOT_CONTAINMENT) ? (size_t)a.H * 4 * 8 * 2 : 0;
+        hipLaunchKernelGGL(wf_tiled_prologue, dim3((unsigned)a.batch), dim3(256), flood_lds, s, a, mode, gx > 1 ? halo : (u64 *)nullptr);
+        if (a.hot_flags & WF_HOT_AUTO_RESET) {
+            hipError_t e = launch_reset_cells(a, mode, MODE_RESET, auto_seed, s);
+            if (e != hipSuccess) return e;
+        }
+        if (a.obs)      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
+            hipLaunchKernelGGL(wf_step_tiled<true>, dim3(gx * (unsigned)a.batch), dim3(256), (size_t)(4 * TR) * a.W * 3 + 16, s, a, mode, acc, (const u64 *)halo);
+        else
+            hipLaunchKernelGGL(wf_step_tiled<false>, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc, (const u64 *)halo);
+        return hipGetLastError();
+    }
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_pre, dim3(eb), dim3(256), 0, s, a, mode);
     if (a.hot_flags & WF_HOT_AUTO_RESET) {
         hipError_t e = launch_reset_cells(a, mode, MODE_RESET, auto_seed, s);
         if (e != hipSuccess) return e;
     }
-    if (fam == WF_FAM_TILED && (a.hot_flags & WF_HOT_CONTAINMENT)) {
-        const size_t lds_bytes = (size_t)a.H * 4 * 8 * 2;
-        hipLaunchKernelGGL(wf_big_flood, dim3((unsigned)a.batch), dim3(256), lds_bytes, s, a, (const uint8_t *)mode);
-    }
-    if (fam == WF_FAM_CELLS && (a.hot_flags & WF_HOT_CONTAINMENT)) {
+    if (a.hot_flags & WF_HOT_CONTAINMENT) {
         const size_t lds_bytes = ((size_t)a.H * a.W + 15) & ~(size_t)15;
         hipLaunchKernelGGL(wf_cells_flood, dim3((unsigned)a.batch), dim3(256), lds_bytes, s, a, (const uint8_t *)mode);
     }
-    if (fam == WF_FAM_TILED) {
-        const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
-        if (halo && gx > 1) {     // in place: save the masks of the rows between workgroups before anyone rewrites them
-            const unsigned tasks = (unsigned)a.batch * gx * 2u;
-            hipLaunchKernelGGL(wf_big_halo, dim3((tasks + 3) / 4), dim3(256), 0, s, a, (const uint8_t *)mode, halo);
-        }
-        if (a.obs)      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
-            hipLaunchKernelGGL(wf_step_tiled<true>, dim3(gx * (unsigned)a.batch), dim3(256), (size_t)(4 * TR) * a.W * 3 + 16, s, a, mode, acc, (const u64 *)halo);
-        else
-            hipLaunchKernelGGL(wf_step_tiled<false>, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc, (const u64 *)halo);
-    } else {
-        const size_t total = (size_t)a.batch * a.H * a.W;
-        size_t blocks = (total + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(wf_step_cells, dim3((unsigned)blocks), dim3(256), 0, s, a, mode, acc);
-    }
+    const size_t total = (size_t)a.batch * a.H * a.W;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wf_step_cells, dim3((unsigned)blocks), dim3(256), 0, s, a, mode, acc);
     hipLaunchKernelGGL(wf_big_post, dim3(eb), dim3(256), 0, s, a, mode, acc);
     return hipGetLastError();
 }
