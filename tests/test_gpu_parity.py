@@ -1243,3 +1243,68 @@ def test_bench_contract_single_and_two_ranks(wf):
     assert r3.returncode == 0, r3.stderr[-2000:]
     d3 = json.loads([l for l in r3.stdout.splitlines() if l.strip().startswith("{")][0])
     assert d3["n_gpus"] == 2 and d3["config"]["global_batch"] == 2 * 16384
+
+
+# ------------------------------------------------------------------ arbitrary uploaded states
+def _random_state(B, H, W, rng, toggle):
+    """Arbitrary (valid) boundary states, not the ones a reset produces: scattered fire with any fuel (0 and 1
+    included: burn-out on the first tick), grass at every heat level below ignition, burnt / dirt / water patches,
+    with the toggle the two extra codes, agents anywhere (visible or not, digging or not)."""
+    planes = np.zeros((B, H, W, 4), dtype=np.int8)
+    kinds = [0, 1, 2, 3, 4] + ([5, 6] if toggle else [])
+    probs = np.array([0.62, 0.10, 0.08, 0.08, 0.06] + ([0.03, 0.03] if toggle else []))
+    t = rng.choice(kinds, size=(B, H, W), p=probs / probs.sum()).astype(np.int8)
+    fuel = rng.integers(1, 45, size=(B, H, W))
+    burning = (t == 1) | (t == 5)
+    fuel[burning] = rng.integers(0, 30, size=int(burning.sum()))
+    heat = rng.integers(0, 19, size=(B, H, W))
+    heat[t == 1] = rng.choice([19, 25], size=int((t == 1).sum()))
+    planes[..., 0], planes[..., 1], planes[..., 2] = t, fuel, heat
+    envs = np.zeros(B, dtype=O.ENV_DTYPE)
+    for b in range(B):
+        ok = np.argwhere(t[b] != 4)
+        y, x = ok[rng.integers(len(ok))]
+        envs[b]["x"], envs[b]["y"] = x, y
+        fl = O.F_ALIVE | O.F_RUNNING | (O.F_DIGGING if rng.random() < 0.6 else 0)
+        if rng.random() < 0.8:
+            fl |= O.F_VISIBLE
+            planes[b, y, x, 3] = 1
+        border = np.concatenate([burning[b, 0], burning[b, -1], burning[b, :, 0], burning[b, :, -1]]).any()
+        if border or rng.random() < 0.1:
+            fl |= O.F_BORDER
+        envs[b]["flags"] = fl
+    return planes, envs
+
+
+@pytest.mark.parametrize("W,H,toggle", [(14, 14, False), (10, 10, True), (12, 12, True), (16, 8, False), (24, 16, True),
+                                        (64, 70, False), (11, 13, True)])
+def test_arbitrary_uploaded_states_match_oracle(wf, W, H, toggle):
+    """Parity on states no reset would produce (uploaded through wf_upload): every kernel family, with and without
+    the dig toggle, 40 steps of random actions from each of several random states."""
+    B = 320
+    md = {"allow_dig_toggle": True, "n_actions": 5} if toggle else None
+    env = wf.BatchedForestFire(B, width=W, height=H, containment=True, metadata=md)
+    op = O.default_params(allow_dig_toggle=int(toggle), containment=1)
+    rng = np.random.default_rng(W * 131 + H)
+    for rep in range(3):
+        planes, envs = _random_state(B, H, W, rng, toggle)
+        env.upload(planes, envs)
+        for t in range(40):
+            a = rng.integers(0, 6, size=B).astype(np.int8)
+            if t % 9 == 8:                                       # a fused multi-step call in between
+                a2 = rng.integers(0, 6, size=(3, B)).astype(np.int8)
+                r3, d3 = env.step_many(a2)
+                for k in range(3):
+                    ro, do = O.step(planes, envs, a2[k], op)
+                    np.testing.assert_array_equal(r3[k], ro, err_msg=f"rep {rep} t={t} fused step {k}: reward")
+                    np.testing.assert_array_equal(d3[k], do.astype(bool), err_msg=f"rep {rep} t={t} fused step {k}: done")
+            else:
+                obs, r, d, _ = env.step(a)
+                ro, do = O.step(planes, envs, a, op)
+                np.testing.assert_array_equal(r, ro, err_msg=f"rep {rep} t={t}: reward")
+                np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"rep {rep} t={t}: done")
+                np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"rep {rep} t={t}: obs")
+            gp, ge = env.download()
+            np.testing.assert_array_equal(gp, planes, err_msg=f"rep {rep} t={t}: planes")
+            np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"rep {rep} t={t}: envs")
+    env.close()
