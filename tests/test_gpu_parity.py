@@ -1256,7 +1256,7 @@ def _random_state(B, H, W, rng, toggle):
     t = rng.choice(kinds, size=(B, H, W), p=probs / probs.sum()).astype(np.int8)
     fuel = rng.integers(1, 45, size=(B, H, W))
     burning = (t == 1) | (t == 5)
-    fuel[burning] = rng.integers(0, 30, size=int(burning.sum()))
+    fuel[burning] = rng.integers(-3, 30, size=int(burning.sum()))     # <= 0: poked states only, burn out at once
     heat = rng.integers(0, 19, size=(B, H, W))
     heat[t == 1] = rng.choice([19, 25], size=int((t == 1).sum()))
     planes[..., 0], planes[..., 1], planes[..., 2] = t, fuel, heat

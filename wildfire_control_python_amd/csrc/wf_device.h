@@ -34,6 +34,16 @@ __device__ __forceinline__ uint32_t addc0(uint32_t a, u64 carry)
     return d;
 }
 
+// c + d in two independent 16-bit halves (v_pk_add_u16).  The fire step of a packed cell word adds 0xFF01 / 0xFF00
+// (fuel byte -1, type byte +1 unless still burning) to the LOW half only: as a 32-bit add of 0xFFFFFF01 it would borrow a
+// heat quantum from the high half whenever the fuel byte is 0 - a state no reset produces (fuel >= 1) but an upload can.
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t c, uint32_t d)
+{
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(c), "v"(d));
+    return r;
+}
+
 // ----------------------------------------------------------------------------
 // counter-based stream (same arithmetic as oracle/wf_oracle.c, written independently)
 // ----------------------------------------------------------------------------

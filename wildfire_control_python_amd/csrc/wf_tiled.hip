@@ -265,9 +265,9 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u64 F = __ballot((c[j] & 3u) == 1u);
-            // fuel -= 1 and fire -> burnt (+0xFFFFFF01) unless still burning (+0xFFFFFF00): the burn-out
-            // lanes arrive as the carry-in of one add
-            c[j] = addc(c[j], lanebit(F) ? 0xFFFFFF00u : 0u, F & ~Sc[j]);
+            // fuel -= 1 and fire -> burnt (low half + 0xFF01) unless still burning (+ 0xFF00); the halves are added
+            // independently, so a burning cell uploaded with fuel 0 borrows nothing from its heat byte
+            c[j] = pk_add_u16(c[j], lanebit(F) ? (lanebit(Sc[j]) ? 0xFF00u : 0xFF01u) : 0u);
             const u64 G = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);   // idle lanes hold inert (dirt) cells
             // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows; every
             // neighbour set is counted by one add-with-carry-in
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
             auto still = [&](uint32_t v) -> uint32_t { return ((v & 3u) == 1u && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
             const uint32_t t = c & 0xffu;
             if ((t & 3u) == 1u) {                                                  // burning: fire or burning dirt
-                c = c + 0xFFFFFF01u - still(c);                                    // reduce_fuel :297-307
+                c = (c & 0xFFFF0000u) | ((c + 0xFF01u - still(c)) & 0xFFFFu);      // reduce_fuel :297-307 (low half only)
             } else if (t == WF_GRASS) {
                 uint32_t cnt = 0;                                                  // get_neighbours :311-326
                 if (x > 0) cnt += still(se[q - 1]);

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
         bgeo |= inner << j;
     }
     asm volatile("" : "+v"(bgeo));
-    const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
+    const uint32_t K_FIRE_STEP = 0x0000FF01u;                // low half: fuel byte -1, type byte +1 (fire -> burnt); pk_add_u16
     __shared__ __attribute__((aligned(16))) uint8_t sObs[SHARED ? 8 : 4][ObsGeo<W, H>::PAD];
     uint8_t *obs_lds = sObs[wv];
     uint32_t oj[4];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                     // fuel -= 1 and fire -> burnt, unless still burning (type stays fire)
                     const uint32_t d = lanebit(STILL[j]) ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
-                    c[j] += lanebit(F) ? d : 0u;
+                    c[j] = pk_add_u16(c[j], lanebit(F) ? d : 0u);
                 }
                 uint32_t ign_bits = 0;
                 static_for<4>([&](auto J) {

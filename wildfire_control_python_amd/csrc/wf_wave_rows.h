@@ -354,7 +354,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                   : ((xs == 0u ? 1u : 0u) | (xs + (uint32_t)CPL == (uint32_t)W ? 1u << (CPL - 1) : 0u));
     uint32_t ob = hh * OBS_BYTES + (xs * H + y) * 3u;         // obs[x][y][k] image of the iteration's environments
     asm volatile("" : "+v"(bgeo), "+v"(ob));
-    const uint32_t K_FIRE_STEP = 0xFFFFFF01u;                // fuel byte -1, type byte +1 (fire -> burnt)
+    const uint32_t K_FIRE_STEP = 0x0000FF01u;                // low half: fuel byte -1, type byte +1 (fire -> burnt); pk_add_u16
     constexpr int OBS_PAD = (EPW * OBS_BYTES + 15) & ~15;
     __shared__ __attribute__((aligned(16))) uint8_t sObs[SHARED ? 8 : 4][OBS_PAD];
     uint8_t *obs_lds = sObs[wv];
@@ -438,7 +438,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                         sv[j] = st ? 1u : 0u;
                         const uint32_t d = st ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
                         const uint32_t dd = lanebit(F) ? d : 0u;
-                        c[j] += dd;
+                        c[j] = pk_add_u16(c[j], dd);
                         chg |= dd;
                     }
                     u64 IGNANY = 0, IGN0 = 0, IGNL = 0;
