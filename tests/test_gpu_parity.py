@@ -732,7 +732,7 @@ def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
 
 def test_config4_1024x256x256_full_size(wf, monkeypatch):
     """BASELINE configs[3] at its stated size: 1 024 batched 256x256 grids, ~1 % of the cells pre-ignited, fuel
-    U{10..40}.  The job takes the two-stream split of the in-place tiled kernel (wf_big_halo -> wf_step_tiled on two
+    U{10..40}.  The job takes the two-stream split of the in-place tiled kernel (wf_tiled_prologue -> wf_step_tiled on two
     shares of the batch); a WF_NO_SPLIT twin must agree bit for bit on every plane, a strided sample of 32
     environments (both shares, the seam and the last env) is replayed by the oracle, and the monotonicity laws
     of the rule are checked on ALL cells.  30 no-op ticks (the configuration), then 12 steps with agents digging."""
