@@ -50,6 +50,41 @@ __device__ __forceinline__ void reset_record(const WfArgs &a, uint32_t e, u64 se
     *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
 }
 
+// One cell of a fresh grid (reset_map environment.py:59-95, set_fire_to :233-246, Agent.__init__ :108-113) under the
+// counter-based stream; river_col = column of the river's water cell in this row (0xffff: none).
+struct ResetLaw { uint32_t W, H, cells, qc, qs, span, ppm; int32_t fuel_lo; };
+
+__device__ __forceinline__ ResetLaw reset_law(const WfArgs &a, const uint4 &ev)
+{
+    const WfCold *cold = a.cold;
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H;
+    ResetLaw L;
+    L.W = W; L.H = H; L.cells = W * H;
+    L.qc = (H / 2u) * W + W / 2u;
+    L.qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
+    L.fuel_lo = cold->p.fuel_lo;
+    L.span = (uint32_t)(cold->p.fuel_hi - cold->p.fuel_lo + 1);
+    L.ppm = cold->p.ignite_ppm;
+    return L;
+}
+
+__device__ __forceinline__ uint32_t reset_cell(const ResetLaw &L, const EnvKey &key, uint32_t q, uint32_t x, uint32_t y,
+                                               uint32_t river_col, bool &border_fire)
+{
+    uint32_t fuel = (uint32_t)L.fuel_lo;
+    if (L.span > 1u) fuel += below(key.draw(16u + q), L.span);
+    uint32_t ty = WF_GRASS, heat = 0, ag = 0;
+    if (river_col == x) ty = WF_WATER;
+    if (q == L.qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
+    if (q == L.qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
+    if (L.ppm && ty == WF_GRASS && below(key.draw(16u + L.cells + q), 1000000u) < L.ppm) {
+        ty = WF_FIRE;
+        heat = WF_HEAT_FORCED;
+        border_fire |= (x == 0 || y == 0 || x == L.W - 1 || y == L.H - 1);
+    }
+    return ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
+}
+
 // ---------------------------------------------------------------------------- pre
 // Agent.move / toggle / death and the containment bookkeeping of ONE environment (run by one lane): applies the touched
 // bytes to the grid, returns the step mode; the updated record is left in `ev` for the caller to write.
@@ -363,15 +398,34 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
     int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
     if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
-        if constexpr (OBS) {                               // ... but its observation is still due
-            if (has_rows && active) {
-                const uint4 *srcq = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
-                for (uint32_t r = r0; r < r1; ++r) {
-                    const uint4 q = srcq[r * LW];
-                    const uint32_t cq[4] = { q.x, q.y, q.z, q.w };
-                    stage_obs_row(ot, r, lane, cq);
+        const bool fresh = (md & MODE_MASK) == MODE_RESET;  // auto-reset: World.reset() of this environment's cells, here
+        if (fresh || OBS) {                                // (a frozen one still owes its observation)
+            uint4 *rows = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+            const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);          // fresh: written by the prologue
+            const EnvKey key(a.cold->p.seed, a.cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
+            const ResetLaw L = reset_law(a, ev);
+            const bool rivers = fresh && a.cold->p.make_rivers != 0;
+            bool border_fire = false;
+            for (uint32_t r = r0; r < r1; ++r) {
+                uint32_t cq[4];
+                if (fresh) {
+                    uint32_t rcol = 0xffffu;
+                    if (rivers) river_cells(key, (int)W, (int)H, [&](int x, int y) { rcol = (uint32_t)y == r ? (uint32_t)x : rcol; });
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cq[j] = reset_cell(L, key, r * W + 4u * lane + (uint32_t)j, 4u * lane + (uint32_t)j, r, rcol, border_fire);
+                    if (active) rows[r * LW] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+                } else if (active) {
+                    const uint4 q = rows[r * LW];
+                    cq[0] = q.x; cq[1] = q.y; cq[2] = q.z; cq[3] = q.w;
+                }
+                if constexpr (OBS) {
+                    if (active) stage_obs_row(ot, r, lane, cq);
                 }
             }
+            if (__ballot(border_fire && active) && lane == 0)
+                atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+        }
+        if constexpr (OBS) {
             __syncthreads();
             flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
         }
@@ -696,11 +750,9 @@ __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const 
     for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const uint32_t e = task / chunks, q0 = (task % chunks) * WF_RESET_CHUNK, q1 = min(q0 + WF_RESET_CHUNK, cells);
         if (sel && sel[e] != (uint8_t)sel_value && !(sel_value < 0 && sel[e])) continue;
-        const int32_t fuel_lo = cold->p.fuel_lo, fuel_hi = cold->p.fuel_hi;
-        const uint32_t span = (uint32_t)(fuel_hi - fuel_lo + 1), ppm = cold->p.ignite_ppm;
-        const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec / wf_big_pre
+        const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);     // written by wf_big_reset_rec / the agent logic
         const EnvKey key(seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
-        const uint32_t qc = (H / 2u) * W + W / 2u, qs = (ev.x >> 16) * W + (ev.x & 0xffffu);
+        const ResetLaw L = reset_law(a, ev);
         uint32_t *pe = a.planes + (size_t)e * cells;
         bool border_fire = false;
         const bool rivers = cold->p.make_rivers != 0;
@@ -712,19 +764,8 @@ __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const 
             __syncthreads();
         }
         for (uint32_t q = q0 + threadIdx.x; q < q1; q += 256u) {
-            uint32_t fuel = (uint32_t)fuel_lo;
-            if (span > 1u) fuel += below(key.draw(16u + q), span);
-            uint32_t ty = WF_GRASS, heat = 0, ag = 0;
-            if (rivers && river_x[q / W] == q % W) ty = WF_WATER;
-            if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
-            if (q == qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
-            if (ppm && ty == WF_GRASS && below(key.draw(16u + cells + q), 1000000u) < ppm) {
-                ty = WF_FIRE;
-                heat = WF_HEAT_FORCED;
-                const uint32_t x = q % W, y = q / W;
-                border_fire |= (x == 0 || y == 0 || x == W - 1 || y == H - 1);
-            }
-            pe[q] = ty | ((fuel & 0xffu) << 8) | (heat << 16) | (ag << 24);
+            const uint32_t x = q % W, y = q / W;
+            pe[q] = reset_cell(L, key, q, x, y, rivers ? (uint32_t)river_x[y] : 0xffffu, border_fire);
         }
         if (__ballot(border_fire) && __lane_id() == 0)
             atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
@@ -761,15 +802,13 @@ bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s)
 {
     if (fam == WF_FAM_TILED) {
-        // prologue (agent logic, reachability flood, outer halos) -> [reset of finished environments] -> the in-place
-        // tick, whose last workgroup per environment also does World.RUNNING / reward / done
+        // prologue (agent logic, reachability flood, outer halos) -> the in-place tick, which also writes the fresh
+        // grids of environments that are being auto-reset and whose last workgroup per environment does
+        // World.RUNNING / reward / done
         const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
         const size_t flood_lds = (a.hot_flags & WF_HOT_CONTAINMENT) ? (size_t)a.H * 4 * 8 * 2 : 0;
         hipLaunchKernelGGL(wf_tiled_prologue, dim3((unsigned)a.batch), dim3(256), flood_lds, s, a, mode, gx > 1 ? halo : (u64 *)nullptr);
-        if (a.hot_flags & WF_HOT_AUTO_RESET) {
-            hipError_t e = launch_reset_cells(a, mode, MODE_RESET, auto_seed, s);
-            if (e != hipSuccess) return e;
-        }
+        (void)auto_seed;       // == cold->p.seed: finished environments are reset by the tick kernel itself
         if (a.obs)      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
             hipLaunchKernelGGL(wf_step_tiled<true>, dim3(gx * (unsigned)a.batch), dim3(256), (size_t)(4 * TR) * a.W * 3 + 16, s, a, mode, acc, (const u64 *)halo);
         else
