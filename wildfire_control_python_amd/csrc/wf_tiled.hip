@@ -406,11 +406,19 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
             const ResetLaw L = reset_law(a, ev);
             const bool rivers = fresh && a.cold->p.make_rivers != 0;
             bool border_fire = false;
+            // reset_map's river: the wave walks it once and keeps the columns of its own 16 rows (0xffff: none) in its
+            // slice of the - here unused - strip-halo LDS words
+            uint16_t *river_col = reinterpret_cast<uint16_t *>(&halo[0][0][0]) + wv * TR;
+            if (rivers) {
+                if (lane < (uint32_t)TR) river_col[lane] = 0xffffu;
+                river_cells(key, (int)W, (int)H, [&](int x, int y) {
+                    if ((uint32_t)y - r0 < (uint32_t)TR && lane == 0) river_col[(uint32_t)y - r0] = (uint16_t)x;
+                });
+            }
             for (uint32_t r = r0; r < r1; ++r) {
                 uint32_t cq[4];
                 if (fresh) {
-                    uint32_t rcol = 0xffffu;
-                    if (rivers) river_cells(key, (int)W, (int)H, [&](int x, int y) { rcol = (uint32_t)y == r ? (uint32_t)x : rcol; });
+                    const uint32_t rcol = rivers ? (uint32_t)river_col[r - r0] : 0xffffu;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cq[j] = reset_cell(L, key, r * W + 4u * lane + (uint32_t)j, 4u * lane + (uint32_t)j, r, rcol, border_fire);
                     if (active) rows[r * LW] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
