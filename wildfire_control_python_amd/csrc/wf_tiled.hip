@@ -2,14 +2,15 @@
 //
 // Same rule as wf_kernels.hip (synchronous integer restatement of
 // Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step of the TILED family
-// (W % 4 == 0, W <= 256) is at most three launches:
+// (W % 4 == 0, W <= 256) is two launches:
 //   wf_tiled_prologue   one workgroup per environment: Agent.move / toggle / death (environment.py:116-171) with
 //                       the dug cell and the agent_pos bytes written straight into the grid; the border-reachability
 //                       flood when a dig may have cut a region off; the still-burning masks of the rows between the
 //                       workgroups of the tick (it runs in place)
-//   wf_big_reset_cells  auto-reset only: World.reset() of the environments that were finished
-//   wf_step_tiled       the CA tick in place (+ the observation, when asked for); per-env reductions by atomics, and the
-//                       last of an environment's workgroups to arrive does World.RUNNING, reward, done, record
+//   wf_step_tiled       the CA tick in place (+ the observation, when asked for; + the fresh rows of environments that
+//                       are being auto-reset); per-env reductions by atomics, and the last of an environment's
+//                       workgroups to arrive does World.RUNNING, reward, done, record
+// (wf_reset: wf_big_reset_rec -> wf_big_reset_cells)
 // and of the GENERIC family (any shape, thread per cell, ping-pong planes):
 //   wf_big_pre -> [wf_big_reset_cells] -> [wf_cells_flood] -> wf_step_cells -> wf_big_post
 //
