@@ -56,7 +56,9 @@ enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4,
         * (environment.py:123-138), which retypes the cell to dirt and blocks it (fire_mobility inf) but leaves
         * it in World.burning_cells: it keeps losing fuel and heating its neighbours, shows as dirt (is_burning()
         * false), and when its fuel is gone reduce_fuel() (:297-307) retypes it to burnt, still blocked.
-        * "Burning" everywhere in this library is (type & 3) == 1, i.e. WF_FIRE or WF_DIRT_BURNING. */
+        * "Burning" in a context created with allow_dig_toggle is (type & 3) == 1, i.e. WF_FIRE or WF_DIRT_BURNING;
+        * contexts without it run kernels that know neither code (do not upload them there, and do not switch the
+        * option off with wf_set_params while such cells exist). */
        WF_DIRT_BURNING = 5,     /* reference: type dirt, member of burning_cells, fire_mobility inf */
        WF_BURNT_BLOCKED = 6 };  /* reference: type burnt, fire_mobility inf (dig() turns it into WF_DIRT) */
 #define WF_HEAT_FORCED 25
