@@ -239,7 +239,7 @@ KERNEL_VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("S", [14, 10])
+@pytest.mark.parametrize("S", [14, 10, 12])
 @pytest.mark.parametrize("variant", list(KERNEL_VARIANTS))
 def test_single_step_kernel_variants_match_oracle(wf, monkeypatch, variant, S):
     for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED", "WF_ROWS"):

@@ -338,6 +338,7 @@ struct StepPlan { int G, kind; };
 template <int W, int H> struct HasRows { static constexpr bool value = false; static constexpr int S = 1; };
 template <> struct HasRows<14, 14> { static constexpr bool value = true; static constexpr int S = 2; };   // 7 cells/lane, 2 envs/iteration
 template <> struct HasRows<10, 10> { static constexpr bool value = true; static constexpr int S = 2; };   // 5 cells/lane, 2 envs/iteration
+template <> struct HasRows<12, 12> { static constexpr bool value = true; static constexpr int S = 2; };   // 6 cells/lane, 2 envs/iteration
 
 template <int W, int H>
 StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
