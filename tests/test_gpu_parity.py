@@ -1308,3 +1308,61 @@ def test_arbitrary_uploaded_states_match_oracle(wf, W, H, toggle):
             np.testing.assert_array_equal(gp, planes, err_msg=f"rep {rep} t={t}: planes")
             np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"rep {rep} t={t}: envs")
     env.close()
+
+
+# ------------------------------------------------ rows layout with an odd number of environments per iteration
+@pytest.mark.parametrize("W,H,group,B", [(8, 8, "7", 4096 + 37), (8, 8, "14", 4096 + 37), (16, 8, "6", 4096 + 37), (8, 16, "3", 4096 + 37),
+                                         (10, 20, "6", 4096 + 37), (8, 8, None, 40000), (10, 20, None, 36000), (16, 8, "12", 9000 + 11)])
+def test_rows_layout_with_odd_environments_per_iteration(wf, monkeypatch, W, H, group, B):
+    """8x8 puts 7 environments side by side in a wave iteration, 16x8 / 8x16 / 10x20 put 3: groups are multiples of
+    that, and split launches cut the batch at multiples of 64 x that.  Ragged last groups, auto-resets, floods and
+    containment payments, single steps and multi-step calls, against the oracle."""
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED", "WF_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    if group:
+        monkeypatch.setenv("WF_GROUP", group)
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=17, auto_reset=True, containment=True, fuel_range=(3, 9))
+    assert env.step_kernel.startswith(f"wf_step_rows<{W},{H},"), env.step_kernel
+    if B >= 8192:
+        assert env.step_launches == 2
+    env.reset(seed=17)
+    op = O.default_params(containment=1, fuel_lo=3, fuel_hi=9)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=17, params=op)
+    rng = np.random.default_rng(W * 7 + H)
+    paid = resets = 0
+    half = B // 2
+    T = 45 if B > 20000 else 70
+    t = 0
+    while t < T:
+        n = 4 if (t % 10 == 9 and B >= 8192) else 1
+        acts = np.empty((n, B), dtype=np.int8)
+        outs = []
+        for k in range(n):
+            a = rng.integers(0, 6, size=B).astype(np.int8)
+            a[:half] = _circle_actions(envs[:half], W, H, rng)
+            acts[k] = a
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, a, op)
+            if stopped.any():
+                O.reset(planes, envs, seed=17, mask=stopped, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+                resets += int(stopped.sum())
+            outs.append((ro, do))
+            paid += int((ro == 1000.0).sum())
+        if n == 1:
+            obs, r1, d1, _ = env.step(acts[0])
+            r, d = r1[None], d1[None]
+            np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        else:
+            r, d = env.step_many(acts)
+        for k in range(n):
+            np.testing.assert_array_equal(r[k], outs[k][0], err_msg=f"reward t={t + k}")
+            np.testing.assert_array_equal(d[k], outs[k][1].astype(bool), err_msg=f"done t={t + k}")
+        if t % 5 == 4 or n > 1:
+            gp, ge = env.download()
+            np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+            np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        t += n
+    assert resets > B // 2 and paid > 0, (resets, paid)
+    env.close()

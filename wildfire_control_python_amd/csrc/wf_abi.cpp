@@ -179,13 +179,20 @@ int push_cold(wf_ctx *c)
     return WF_OK;
 }
 
+// environments per part of a split launch
+int split_per(const wf_ctx *c)
+{
+    const int al = wf_split_align(c->W, c->H, c->knobs);
+    return ((c->batch + c->n_parts - 1) / c->n_parts + al - 1) / al * al;
+}
+
 // Is an n_steps call of this (split) context served by the rows kernel's own step loop?  Probed with the FIRST part's
 // shape (the largest one); every part then runs the same kernel.
 bool multi_rows_call(const wf_ctx *c, int n_steps)
 {
     WfArgs probe = base_args(c);
     probe.n_steps = n_steps;
-    probe.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+    probe.batch = split_per(c);
     if (probe.group <= 0) probe.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);
     return wf_multi_step_in_rows(c->fam, probe, c->knobs, c->num_cus);
 }
@@ -481,7 +488,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
                 for (int i = 0; i < c->n_parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
                 c->main_touched = false;
             }
-            const int per = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+            const int per = split_per(c);
             if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);   // as for the whole batch
             for (int i = 0; i < c->n_parts; ++i) {
                 const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
@@ -648,7 +655,7 @@ const char *wf_step_kernel_name(const wf_ctx *c)
     WfArgs a = base_args(c);
     if (splits(c, 1)) {
         if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);
-        a.batch = ((c->batch + c->n_parts - 1) / c->n_parts + 63) & ~63;
+        a.batch = split_per(c);
     }
     return wf_single_step_kernel(c->fam, a, c->knobs, c->num_cus);
 }

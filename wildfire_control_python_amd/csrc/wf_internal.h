@@ -92,6 +92,8 @@ static inline int wf_pick_group(int cells, int num_cus, long long batch)
 // resident slots beat longer waves at every batch from 131 072 up (75 vs 69 % of roofline at 131 072 x 14x14,
 // 80 vs 75 % at 262 144; a wash once the state outgrows the memory-side cache).
 int wf_pick_group_for(int W, int H, int num_cus, long long batch, const WfKnobs &k);
+int wf_rows_epw(int W, int H, const WfKnobs &k);        // environments per iteration of the shape's rows-layout kernel (0: none)
+int wf_split_align(int W, int H, const WfKnobs &k);     // split launches cut the batch at multiples of this
 
 // Launchers; all asynchronous on `s`.  Return hipSuccess or the launch error.
 const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus);

@@ -339,6 +339,12 @@ template <int W, int H> struct HasRows { static constexpr bool value = false; st
 template <> struct HasRows<14, 14> { static constexpr bool value = true; static constexpr int S = 2; };   // 7 cells/lane, 2 envs/iteration
 template <> struct HasRows<10, 10> { static constexpr bool value = true; static constexpr int S = 2; };   // 5 cells/lane, 2 envs/iteration
 template <> struct HasRows<12, 12> { static constexpr bool value = true; static constexpr int S = 2; };   // 6 cells/lane, 2 envs/iteration
+// shapes whose layout puts an ODD number of environments side by side: groups (and split boundaries) are multiples of it
+template <> struct HasRows<8, 8> { static constexpr bool value = true; static constexpr int S = 1; };     // 8 cells/lane, 7 envs/iteration
+template <> struct HasRows<16, 8> { static constexpr bool value = true; static constexpr int S = 2; };    // 8 cells/lane, 3 envs/iteration
+template <> struct HasRows<8, 16> { static constexpr bool value = true; static constexpr int S = 1; };    // 8 cells/lane, 3 envs/iteration
+template <> struct HasRows<10, 20> { static constexpr bool value = true; static constexpr int S = 1; };   // 10 cells/lane, 3 envs/iteration
+// (16x16 and 20x10 would need 5.3 / 5 cell slots per environment against the group layout's 4: no rows kernel)
 
 template <int W, int H>
 StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
@@ -437,15 +443,33 @@ void wf_read_knobs(WfKnobs *k)
     k->multi_rows = 0;
 }
 
-int wf_pick_group_for(int W, int H, int num_cus, long long batch, const WfKnobs &k)
+// environments per wave iteration of the shape's rows-layout kernel (0: the shape has none, or WF_NO_ROWS)
+int wf_rows_epw(int W, int H, const WfKnobs &k)
 {
-    int G = wf_pick_group(W * H, num_cus, batch);
-    bool rows = false;
-#define X(w, h) if (W == w && H == h) rows = HasRows<w, h>::value;
+    int epw = 0;
+#define X(w, h) if (W == w && H == h) { if constexpr (HasRows<w, h>::value) epw = RG<w, h, HasRows<w, h>::S>::EPW; }
     WF_WAVE_SHAPES(X)
 #undef X
-    if (rows && !k.no_rows && G > 8) G = 8;
+    return k.no_rows ? 0 : epw;
+}
+
+int wf_pick_group_for(int W, int H, int num_cus, long long batch, const WfKnobs &k)
+{
+    int G = wf_pick_group(W * H, num_cus, batch);          // a power of two
+    const int epw = wf_rows_epw(W, H, k);
+    if (epw) {
+        if (G > 8) G = 8;
+        if (G >= epw) G = G / epw * epw;                   // a whole number of iterations: 8 -> 6 (3 per iteration), 8 -> 7
+    }
     return G;
+}
+
+// Split launches cut the batch at multiples of this many environments: a wave's first environment must start an
+// iteration of the rows layout in every part (the boards are indexed per iteration of the whole context).
+int wf_split_align(int W, int H, const WfKnobs &k)
+{
+    const int epw = wf_rows_epw(W, H, k);
+    return (epw > 1 && (epw & 1)) ? 64 * epw : 64;
 }
 
 const char *wf_family_name(WfFamily f, int, int)
