@@ -13,12 +13,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwf_oracle.so")
 
-ENV_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("flags", "<u2"), ("reserved", "<u2"),
+ENV_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("flags", "<u2"), ("wind", "<u2"),
                       ("episode", "<u4"), ("tick", "<u4")])
 assert ENV_DTYPE.itemsize == 16
 
 F_ALIVE, F_VISIBLE, F_DIGGING, F_DEAD, F_RUNNING, F_BORDER, F_CONTAINED = 1, 2, 4, 8, 16, 32, 64
 HEAT_FORCED = 25
+HEAT_IGNITED = 24        # wind_mode != 0: plane 2 of a cell ignited by accumulated heat
 
 
 class Params(ctypes.Structure):
@@ -28,7 +29,14 @@ class Params(ctypes.Structure):
                 ("contained_bonus", ctypes.c_double), ("default_reward", ctypes.c_double),
                 ("allow_dig_toggle", ctypes.c_int32), ("containment", ctypes.c_int32),
                 ("fuel_lo", ctypes.c_int32), ("fuel_hi", ctypes.c_int32),
-                ("ignite_ppm", ctypes.c_uint32), ("make_rivers", ctypes.c_int32)]
+                ("ignite_ppm", ctypes.c_uint32), ("make_rivers", ctypes.c_int32),
+                ("wind_mode", ctypes.c_int32), ("wind_code", ctypes.c_int32),
+                ("wind_speeds", ctypes.c_double * 4)]
+
+
+def wind_code(wx, wy, speed_index=0):
+    """wfo_env.wind of a wind vector (wx, wy) in {-1,0,1}^2 and an index into Params.wind_speeds."""
+    return (int(wx) + 1) | (int(wy) + 1) << 2 | int(speed_index) << 4
 
 
 def build(force=False):
@@ -54,6 +62,10 @@ def lib():
                                ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(Params),
                                ctypes.c_void_p, ctypes.c_void_p]
         L.wfo_step.restype = ctypes.c_int
+        L.wfo_step_wind.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, i8p, envp, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(Params),
+                                    ctypes.c_void_p, ctypes.c_void_p]
+        L.wfo_step_wind.restype = ctypes.c_int
         L.wfo_reset.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, i8p, envp,
                                 ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                 ctypes.POINTER(Params)]
@@ -78,6 +90,10 @@ def default_params(**kw):
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
+        if k == "wind_speeds":
+            for i, x in enumerate(v):
+                p.wind_speeds[i] = x
+            continue
         setattr(p, k, v)
     return p
 
@@ -86,8 +102,9 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-def step(planes, envs, actions=None, params=None, do_update=True):
-    """One reference step per env, in place.  planes int8 (B,H,W,4); envs ENV_DTYPE (B,)."""
+def step(planes, envs, actions=None, params=None, do_update=True, counts=None):
+    """One reference step per env, in place.  planes int8 (B,H,W,4); envs ENV_DTYPE (B,);
+    counts uint8 (B,H,W,4) with params.wind_mode != 0 (see wf_oracle.h)."""
     B, H, W, P = planes.shape
     assert P == 4 and planes.dtype == np.int8 and planes.flags.c_contiguous
     if actions is not None:
@@ -96,16 +113,20 @@ def step(planes, envs, actions=None, params=None, do_update=True):
     reward = np.zeros(B, dtype=np.float64)
     done = np.zeros(B, dtype=np.uint8)
     p = params if params is not None else default_params()
-    rc = lib().wfo_step(B, H, W, planes, envs, _ptr(actions), int(bool(do_update)),
-                        ctypes.byref(p), _ptr(reward), _ptr(done))
+    if counts is not None:
+        assert counts.shape == planes.shape and counts.dtype == np.uint8 and counts.flags.c_contiguous
+    rc = lib().wfo_step_wind(B, H, W, planes, envs, _ptr(counts), _ptr(actions), int(bool(do_update)),
+                             ctypes.byref(p), _ptr(reward), _ptr(done))
     assert rc == 0
     return reward, done
 
 
-def reset(planes, envs, seed, mask=None, env_id0=0, params=None):
+def reset(planes, envs, seed, mask=None, env_id0=0, params=None, counts=None):
     B, H, W, P = planes.shape
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    if counts is not None:        # a fresh grid has received no heat
+        counts[slice(None) if mask is None else mask != 0] = 0
     p = params if params is not None else default_params()
     rc = lib().wfo_reset(B, H, W, planes, envs, _ptr(mask), int(seed), int(env_id0),
                          ctypes.byref(p))

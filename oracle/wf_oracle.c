@@ -36,6 +36,12 @@ void wfo_default_params(wfo_params *p)
     p->fuel_lo = 20;               /* utility.py:99  */
     p->fuel_hi = 20;
     p->ignite_ppm = 0;
+    p->wind_mode = 0;
+    p->wind_code = WFO_WIND_CODE(0, 0, 0);
+    p->wind_speeds[0] = 0.0;       /* environment.py:189 */
+    p->wind_speeds[1] = 0.7;
+    p->wind_speeds[2] = 0.85;
+    p->wind_speeds[3] = 0.0;
 }
 
 /* ------------------------------------------------------- counter-based RNG */
@@ -187,7 +193,26 @@ typedef struct {
     int ax, ay;
     int alive, visible, digging, dead, running, fire_at_border, contained;
     double quantum;     /* one heat addend: wind_speed*heat*(0+1)^-1 */
+    /* World.wind_speed / wind_vector (environment.py:187-193) */
+    double wind_speed, wind_x, wind_y;
+    /* wind_mode != 0: addends received per direction, [4*cell + k] (exchange format, see wf_oracle.h) */
+    uint8_t *cnt;
 } world;
+
+/* direction index of the vector (cx, cy) = heated cell - burning cell, in the order of _direction_to_coords */
+static int dir_index(int cx, int cy)
+{
+    return cy < 0 ? 0 : cy > 0 ? 1 : cx > 0 ? 2 : 3;
+}
+
+/* the addend apply_heat_from_to computes for that vector (environment.py:260-287) */
+static double heat_addend(const world *w, double cx, double cy, double distance)
+{
+    double wx = w->wind_x, wy = w->wind_y;
+    double angle = fabs(atan2(wx * cy - wy * cx, wx * cx + wy * cy));   /* :273 */
+    double env_factor = pow(angle + distance, -1.0);                    /* :286 */
+    return w->wind_speed * w->p->heat * env_factor;                     /* :287 */
+}
 
 static int inbounds(const world *w, int x, int y)           /* environment.py:225-226 */
 {
@@ -272,13 +297,12 @@ static void apply_heat_from_to(world *w, int x, int y, int ox, int oy)   /* envi
 {
     /* get_distance_and_angle, manhattan (:260-275) */
     double cx = ox - x, cy = oy - y;
-    double wx = w->p->wind_x, wy = w->p->wind_y;
     double distance = fabs((double)(x - ox)) + fabs((double)(y - oy));
-    double angle = fabs(atan2(wx * cy - wy * cx, wx * cx + wy * cy));
-    double env_factor = pow(angle + distance, -1.0);          /* :286 */
-    double calculated_heat = w->p->wind_speed * w->p->heat * env_factor;   /* :287 */
+    double calculated_heat = heat_addend(w, cx, cy, distance);
     int o = oy * w->W + ox;
     w->temp[o] += calculated_heat;                           /* :290 */
+    if (w->cnt && w->cnt[4 * o + dir_index(ox - x, oy - y)] < 255)
+        w->cnt[4 * o + dir_index(ox - x, oy - y)] += 1;
     if (w->temp[o] > w->p->threshold)                        /* :293-294 */
         set_fire_to(w, ox, oy);
 }
@@ -390,6 +414,10 @@ static int world_alloc(world *w, int H, int W, const wfo_params *p)
     w->queue = malloc(n * sizeof(int));
     w->seen = malloc(n);
     w->quantum = p->wind_speed * p->heat * pow(0.0 + 1.0, -1.0);
+    w->wind_speed = p->wind_speed;                           /* environment.py:192-193 */
+    w->wind_x = p->wind_x;
+    w->wind_y = p->wind_y;
+    w->cnt = NULL;
     return w->type && w->temp && w->fuel && w->agent_pos && w->fmob_inf && w->in_burning && w->burning && w->queue && w->seen;
 }
 
@@ -410,10 +438,40 @@ static double temp_from_count(const world *w, int q)
     return t;
 }
 
-static void decode(world *w, const int8_t *pl, const wfo_env *e)
+/* wind_mode != 0: the environment's own wind (wf_oracle.h) */
+static void take_wind(world *w, const wfo_env *e)
+{
+    if (!w->p->wind_mode)
+        return;
+    w->wind_speed = w->p->wind_speeds[(e->wind >> 4) & 3];
+    w->wind_x = (double)((int)(e->wind & 3) - 1);
+    w->wind_y = (double)((int)((e->wind >> 2) & 3) - 1);
+}
+
+/* wind_mode != 0: temperature of a cell from its marker byte and per-direction counts */
+static double temp_from_wind_counts(const world *w, int marker, const uint8_t *cnt)
+{
+    static const int dcx[4] = { 0, 0, 1, -1 }, dcy[4] = { -1, 1, 0, 0 };
+    double t = 0.0;
+    int k, i;
+    if (marker == WFO_HEAT_FORCED)
+        return w->p->threshold + 1;
+    if (marker == WFO_HEAT_IGNITED)
+        return w->p->threshold + 0.5;       /* some value above the threshold; never read again (a cell burns once) */
+    for (k = 0; k < 4; ++k) {
+        double c = heat_addend(w, dcx[k], dcy[k], 1.0);
+        for (i = 0; i < cnt[k]; ++i)
+            t += c;
+    }
+    return t;
+}
+
+static void decode(world *w, const int8_t *pl, const wfo_env *e, uint8_t *counts)
 {
     int n = w->W * w->H, i;
     w->n_burning = 0;
+    w->cnt = w->p->wind_mode ? counts : NULL;
+    take_wind(w, e);
     for (i = 0; i < n; ++i) {
         int t = pl[4 * i + WFO_P_TYPE];
         /* boundary codes 5 / 6 (see wf_oracle.h): reference type dirt + member of burning_cells / reference
@@ -421,7 +479,8 @@ static void decode(world *w, const int8_t *pl, const wfo_env *e)
         w->type[i] = t == WFO_DIRT_BURNING ? WFO_DIRT : t == WFO_BURNT_BLOCKED ? WFO_BURNT : t;
         w->fmob_inf[i] = t >= WFO_DIRT;
         w->fuel[i] = pl[4 * i + WFO_P_FUEL];
-        w->temp[i] = temp_from_count(w, pl[4 * i + WFO_P_HEAT]);
+        w->temp[i] = w->cnt ? temp_from_wind_counts(w, pl[4 * i + WFO_P_HEAT], w->cnt + 4 * i)
+                            : temp_from_count(w, pl[4 * i + WFO_P_HEAT]);
         w->agent_pos[i] = pl[4 * i + WFO_P_AGENT];
         if (t == WFO_FIRE || t == WFO_DIRT_BURNING)
             w->burning[w->n_burning++] = i;
@@ -450,7 +509,14 @@ static void encode(const world *w, int8_t *pl, wfo_env *e)
         if (t == WFO_BURNT && w->fmob_inf[i]) t = WFO_BURNT_BLOCKED;
         pl[4 * i + WFO_P_TYPE] = (int8_t)t;
         pl[4 * i + WFO_P_FUEL] = (int8_t)w->fuel[i];
-        pl[4 * i + WFO_P_HEAT] = (int8_t)lrint(w->temp[i] / w->quantum);
+        if (w->cnt) {
+            pl[4 * i + WFO_P_HEAT] = w->temp[i] == w->p->threshold + 1 ? WFO_HEAT_FORCED
+                                   : w->temp[i] > w->p->threshold ? WFO_HEAT_IGNITED : 0;
+            if (t != WFO_GRASS)
+                memset(w->cnt + 4 * i, 0, 4);
+        } else {
+            pl[4 * i + WFO_P_HEAT] = (int8_t)lrint(w->temp[i] / w->quantum);
+        }
         pl[4 * i + WFO_P_AGENT] = w->agent_pos[i];
     }
     e->x = (uint16_t)w->ax;
@@ -467,10 +533,19 @@ int wfo_step(int batch, int H, int W, int8_t *planes, wfo_env *envs,
              const int8_t *actions, int do_update, const wfo_params *p,
              double *reward, uint8_t *done)
 {
+    return wfo_step_wind(batch, H, W, planes, envs, NULL, actions, do_update, p, reward, done);
+}
+
+int wfo_step_wind(int batch, int H, int W, int8_t *planes, wfo_env *envs, uint8_t *counts,
+                  const int8_t *actions, int do_update, const wfo_params *p,
+                  double *reward, uint8_t *done)
+{
     world w;
     int b;
     size_t stride = (size_t)H * (size_t)W * 4;
     if (batch < 0 || H <= 0 || W <= 0 || !planes || !envs || !p)
+        return -1;
+    if ((p->wind_mode != 0) != (counts != NULL))
         return -1;
     if (!world_alloc(&w, H, W, p)) {
         world_free(&w);
@@ -486,7 +561,7 @@ int wfo_step(int batch, int H, int W, int8_t *planes, wfo_env *envs,
             if (done) done[b] = 1;
             continue;
         }
-        decode(&w, pl, e);
+        decode(&w, pl, e, counts ? counts + stride * (size_t)b : NULL);
         /* ForestFire.step, forest_fire.py:30-49 */
         if (a >= 0 && a <= 3)                    /* :32-33 */
             agent_move(&w, a);
@@ -532,7 +607,18 @@ int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
         if (mask && !mask[b])
             continue;
         ep = e->episode;
-        /* World.reset environment.py:186-212; reset_map :59-67 */
+        /* World.reset environment.py:186-212: wind :187-193 */
+        e->wind = 0;
+        if (p->wind_mode == 1)
+            e->wind = (uint16_t)p->wind_code;
+        if (p->wind_mode == 2) {                             /* :189-190, three uniform draws */
+            unsigned si = below(wfo_rng_u32(seed, id, ep, 2), 3);
+            int wx = (int)below(wfo_rng_u32(seed, id, ep, 3), 3) - 1;
+            int wy = (int)below(wfo_rng_u32(seed, id, ep, 4), 3) - 1;
+            e->wind = (uint16_t)WFO_WIND_CODE(wx, wy, si);
+        }
+        w.cnt = NULL;                                        /* a fresh grid has received no heat: the caller zeroes counts */
+        /* reset_map :59-67 */
         w.running = 1;                                       /* :196 */
         for (i = 0; i < n; ++i) {
             w.type[i] = 0;
@@ -583,7 +669,6 @@ int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
         encode(&w, planes + stride * (size_t)b, e);
         e->episode = ep + 1;
         e->tick = 0;
-        e->reserved = 0;
     }
     world_free(&w);
     return 0;

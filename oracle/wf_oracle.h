@@ -25,6 +25,17 @@
  *            wind_speed*heat (environment.py:286-290); q == WFO_HEAT_FORCED <->
  *            temp = threshold+1 written by set_fire_to() on a cold cell (:236-237).
  *   envs   : one wfo_env per environment (agent + world scalars).
+ *
+ * Wind (wind_mode != 0; METADATA['wind'] = [speed, (wx, wy)] with a non-zero vector, or "random",
+ * environment.py:187-193): the heat addend depends on the direction burning cell -> heated cell
+ * (get_distance_and_angle :260-275), so a cell's temperature is no longer a multiple of one quantum.  The
+ * exchange format then carries, next to the planes, counts uint8 (batch, H, W, 4): how many addends a GRASS
+ * cell has received per direction k of the vector (cx, cy) = heated cell - burning cell, k = 0 (0,-1),
+ * 1 (0,+1), 2 (+1,0), 3 (-1,0) (the order of _direction_to_coords, :163-171); zero for every other cell.
+ * temp = the float64 running sum of those addends, k ascending.  Plane 2 then only says how a cell was
+ * ignited: 0 never, WFO_HEAT_FORCED by set_fire_to() on a cold cell, WFO_HEAT_IGNITED by accumulated heat.
+ * The wind of an environment sits in wfo_env.wind = (wx+1) | (wy+1) << 2 | speed index << 4, the index
+ * selecting wfo_params.wind_speeds[].
  */
 #ifndef WF_ORACLE_H
 #define WF_ORACLE_H
@@ -57,7 +68,7 @@ enum {
 typedef struct {
     uint16_t x, y;       /* agent position (valid while ALIVE)            */
     uint16_t flags;      /* WFO_F_*                                        */
-    uint16_t reserved;
+    uint16_t wind;       /* wind code (wind_mode != 0), see above           */
     uint32_t episode;    /* number of resets this env has seen             */
     uint32_t tick;       /* update() calls since the last reset            */
 } wfo_env;
@@ -76,9 +87,17 @@ typedef struct {
     int32_t fuel_lo, fuel_hi;
     uint32_t ignite_ppm;     /* extra pre-ignited grass cells per million  */
     int32_t make_rivers;     /* constants.py:44: reset_map draws a river (environment.py:69-95) */
+    /* 0: wind_speed / wind_x / wind_y above for every environment (the reference's default has vector (0,0)).
+     * 1: every environment carries its own wind (wfo_env.wind); wfo_reset writes wind_code.
+     * 2: METADATA['wind'] == "random" (environment.py:188-190): wfo_reset draws speed index and vector. */
+    int32_t wind_mode;
+    int32_t wind_code;
+    double wind_speeds[4];   /* environment.py:189  {0, 0.7, 0.85} for "random" */
 } wfo_params;
 
 #define WFO_HEAT_FORCED 25
+#define WFO_HEAT_IGNITED 24
+#define WFO_WIND_CODE(wx, wy, si) ((unsigned)((wx) + 1) | (unsigned)((wy) + 1) << 2 | (unsigned)(si) << 4)
 
 void wfo_default_params(wfo_params *p);
 
@@ -91,6 +110,11 @@ void wfo_default_params(wfo_params *p);
 int wfo_step(int batch, int H, int W, int8_t *planes, wfo_env *envs,
              const int8_t *actions, int do_update, const wfo_params *p,
              double *reward, uint8_t *done);
+
+/* The same with wind (wind_mode != 0): counts uint8 (batch, H, W, 4) in/out, see the top of this file. */
+int wfo_step_wind(int batch, int H, int W, int8_t *planes, wfo_env *envs, uint8_t *counts,
+                  const int8_t *actions, int do_update, const wfo_params *p,
+                  double *reward, uint8_t *done);
 
 /* World.reset() per environment where mask[i] != 0 (mask NULL = all), with the
  * build's counter-based stream keyed by (seed, env_id0 + i, episode) replacing

@@ -45,6 +45,7 @@ ASTAR_SO = os.path.join(REPO, "oracle", "_ref", "astar.so")
 # plane order of the build's int8 (batch,H,W,4) state buffer
 P_TYPE, P_FUEL, P_HEAT, P_AGENT = 0, 1, 2, 3
 HEAT_FORCED = 25  # round((threshold+1)/0.162): set_fire_to() on a cold cell, environment.py:236-237
+HEAT_IGNITED = 24  # wind fixtures: plane 2 only says how a cell was ignited (0 never / forced / by accumulated heat)
 
 
 def _install_stand_ins():
@@ -99,8 +100,9 @@ def _install_stand_ins():
 class Recorder:
     """Collects one fixture file worth of episodes."""
 
-    def __init__(self, sim, layer, size):
-        self.sim, self.layer, self.size = sim, layer, size
+    def __init__(self, sim, layer, size, wind=False):
+        self.sim, self.layer, self.size, self.wind = sim, layer, size, wind
+        self.winds, self.temps = [], []
         self.c = 0.54 * 0.3 * (0 + 1) ** (-1)  # environment.py:286-287 with wind (0,0)
         self.rows = {k: [] for k in ("planes", "agent", "reward", "done", "obs",
                                      "fab", "border_len", "action")}
@@ -116,14 +118,19 @@ class Recorder:
         W = self.sim.W
         env, L = W.env, self.layer
         temp = env[:, :, L["temp"]]
-        q = np.rint(temp / self.c).astype(np.int64)
-        # the float64 temperature must be exactly the running sum of q equal addends
-        # (order independence claim of SURVEY 8a) or the forced value threshold+1
-        for (x, y), v in np.ndenumerate(q):
-            t = temp[x, y]
-            if v == HEAT_FORCED and t == 4.0:
-                continue
-            assert t == self._seqsum(v), (x, y, t, v)
+        if self.wind:
+            # direction-dependent addends (environment.py:260-287): the temperature is no multiple of one quantum;
+            # plane 2 records how the cell was ignited, the float temperatures go into their own array
+            q = np.where(temp == 4.0, HEAT_FORCED, np.where(temp > 3.0, HEAT_IGNITED, 0))
+        else:
+            q = np.rint(temp / self.c).astype(np.int64)
+            # the float64 temperature must be exactly the running sum of q equal addends
+            # (order independence claim of SURVEY 8a) or the forced value threshold+1
+            for (x, y), v in np.ndenumerate(q):
+                t = temp[x, y]
+                if v == HEAT_FORCED and t == 4.0:
+                    continue
+                assert t == self._seqsum(v), (x, y, t, v)
         p = np.zeros((self.size, self.size, 4), dtype=np.int8)  # [y, x, plane]
         code = env[:, :, L["type"]].astype(np.int64)         # [x, y]
         fm = env[:, :, L["fire_mobility"]]
@@ -158,6 +165,9 @@ class Recorder:
         self.init_planes.append(self._planes())
         self.init_agent.append(self._agent())
         self.init_world.append([int(self.sim.W.fire_at_border), len(self.sim.W.border_points)])
+        if self.wind:
+            W = self.sim.W
+            self.winds.append([float(W.wind_speed), float(W.wind_vector[0]), float(W.wind_vector[1])])
 
     def step(self, action):
         state, reward, done, _ = self.sim.step(action)
@@ -170,12 +180,19 @@ class Recorder:
         r["fab"].append(bool(self.sim.W.fire_at_border))
         r["border_len"].append(len(self.sim.W.border_points))
         r["action"].append(int(action))
+        if self.wind:
+            self.temps.append(self.sim.W.env[:, :, self.layer["temp"]].T.astype(np.float32))   # [y, x]
         return state, reward, done
 
     def save(self, path):
         r = self.rows
+        extra = {}
+        if self.wind:
+            extra = dict(wind=np.asarray(self.winds, dtype=np.float64),       # per episode: speed, wx, wy
+                         temp=np.asarray(self.temps, dtype=np.float32))      # per step: World.env[:, :, temp] as [y, x]
         np.savez_compressed(
             path,
+            **extra,
             size=np.int32(self.size),
             ep_start=np.asarray(self.ep_start + [len(r["action"])], dtype=np.int64),
             init_planes=np.asarray(self.init_planes, dtype=np.int8),
@@ -370,6 +387,30 @@ def run_size(size):
     seen = np.asarray(rec.rows["planes"])[..., P_TYPE]
     assert (seen == 5).any() and (seen == 6).any(), "the toggle fixture must contain burning-dirt and blocked-burnt cells"
     rec.save(out("toggle"))
+
+    # 8. METADATA['wind'] = "random" (environment.py:188-190): per-episode wind speed in {0, 0.7, 0.85} and vector in
+    #    {-1,0,1}^2; the heat addend then depends on the direction burning cell -> neighbour (:260-287)
+    rec = Recorder(sim, layer, size, wind=True)
+    rng = np.random.default_rng(7000 + size)
+    constants.METADATA["wind"] = "random"
+    for ep in range(40):
+        reset(700 + ep)
+        if ep % 5 == 4:
+            sim.W.env[:, :, layer["fuel"]] = rng.integers(10, 41, size=(size, size)).astype(np.float64)
+        rec.begin(700 + ep)
+        done = False
+        while not done:
+            if ep % 3 == 0:
+                a = NOOP
+            elif ep % 3 == 1:
+                a = int(rng.integers(0, 4)) if rng.random() > 0.3 else NOOP
+            else:
+                a = circling_policy(sim, rng)
+            _, _, done = rec.step(a)
+    constants.METADATA["wind"] = [0.54, (0, 0)]
+    seen = {tuple(w) for w in rec.winds}
+    assert len({w[0] for w in seen}) == 3 and len({w[1:] for w in seen}) >= 8, seen
+    rec.save(out("wind"))
 
 
 def main():

@@ -9,6 +9,7 @@ import numpy as np
 from oracle import oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+WIND_SPEEDS = [0.0, 0.7, 0.85]        # environment.py:189
 
 
 def fixture_files(size=None):
@@ -35,7 +36,41 @@ class Episodes:
         iw = d["init_world"]
         e["flags"] = (O.F_ALIVE | O.F_VISIBLE | O.F_DIGGING | O.F_RUNNING) \
             | (iw[:, 0] != 0) * O.F_BORDER | (iw[:, 1] == 0) * O.F_CONTAINED
+        # wind fixtures (METADATA['wind'] = "random"): the episode's wind as the env's wind code, speed index into
+        # WIND_SPEEDS; the per-direction heat counts start at zero (a fresh grid has received no heat)
+        self.wind = "wind" in d.files
+        if self.wind:
+            w = d["wind"]
+            si = np.array([WIND_SPEEDS.index(float(v)) for v in w[:, 0]])
+            e["wind"] = (w[:, 1].astype(int) + 1) | (w[:, 2].astype(int) + 1) << 2 | si << 4
         self.init_envs = e
+
+    def oracle_params(self, **kw):
+        """Oracle parameters as the generator configured the reference for this file."""
+        if "toggle" in self.name:
+            kw.setdefault("allow_dig_toggle", 1)           # constants.py:46
+        if self.wind:
+            kw.update(wind_mode=1, wind_speeds=WIND_SPEEDS + [0.0])
+        return O.default_params(**kw)
+
+    def wind_addends(self):
+        """float64 (B, 4): the heat addend per direction k of every episode, computed like
+        environment.py:260-287 (direction k = vector from the burning cell to the heated one: N, S, E, W)."""
+        import math
+        out = np.zeros((self.B, 4))
+        for b, (sp, wx, wy) in enumerate(self.d["wind"]):
+            for k, (cx, cy) in enumerate(((0, -1), (0, 1), (1, 0), (-1, 0))):
+                angle = abs(math.atan2(wx * cy - wy * cx, wx * cx + wy * cy))
+                out[b, k] = sp * 0.3 * (angle + 1) ** (-1)
+        return out
+
+    def check_temp(self, t, planes, counts, what="oracle"):
+        """Wind fixtures: the recorded float temperature of every GRASS cell is the sum of its counted addends."""
+        exp, live = self.expected_at(t, "temp")
+        got = (counts[live].astype(np.float64) * self.wind_addends()[live][:, None, None, :]).sum(axis=-1)
+        grass = planes[live][..., 0] == 0
+        np.testing.assert_allclose(got[grass], exp[grass], rtol=0, atol=2e-6, err_msg=f"{self.name} step {t} ({what}) temp")
+        assert not counts[live][~grass].any(), "counts of cells that are not grass are zero"
 
     def actions_at(self, t):
         """int8 (B,) actions of step t (no-op 5 where the episode is over)."""

@@ -16,12 +16,15 @@ def test_oracle_reproduces_reference(path):
     planes = ep.init_planes.copy()
     envs = ep.init_envs.copy()
     n_contained = n_burning_dirt = 0
-    op = O.default_params(allow_dig_toggle=int("toggle" in path))      # constants.py:46 as the generator set it
+    op = ep.oracle_params()                  # toggle / wind as the generator set them (constants.py:39,46)
+    counts = np.zeros(planes.shape, np.uint8) if ep.wind else None
     for t in range(ep.T):
         actions, _ = ep.actions_at(t)
-        reward, done = O.step(planes, envs, actions, op)
+        reward, done = O.step(planes, envs, actions, op, counts=counts)
         obs = O.get_state(planes)
         live = ep.check_step(t, planes, envs, reward, done, obs)
+        if ep.wind:
+            ep.check_temp(t, planes, counts)
         n_contained += int((reward[live] == 1000.0).sum())
         n_burning_dirt += int((planes[live][..., 0] == 5).sum())
     if "circle" in path:

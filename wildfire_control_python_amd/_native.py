@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WILDFIRE_LIB") or os.path.join(HERE, "libwildfire_hip.so")   # override: A/B builds
 
-ENV_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("flags", "<u2"), ("reserved", "<u2"),
+ENV_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("flags", "<u2"), ("wind", "<u2"),
                       ("episode", "<u4"), ("tick", "<u4")])
 assert ENV_DTYPE.itemsize == 16
 
