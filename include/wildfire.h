@@ -31,6 +31,7 @@
  *                            (environment.py:286-290); WF_HEAT_FORCED marks
  *                            temp = threshold+1 written by set_fire_to (:236-237)
  *             plane 3 agent  agent_pos layer (utility.py:121)
+ *   counts  only with wind (wf_params.wind_mode != 0): uint8 (batch, H, W, 4), see wf_wind_counts_upload
  *   envs    wf_env[batch]: agent and world scalars (Agent.x/.y/.dead/.digging,
  *           World.RUNNING/.fire_at_border, "border deque exhausted")
  *   actions int8: 0..3 = N,S,E,W (environment.py:163-171); 4 = dig toggle when
@@ -48,7 +49,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 1
+#define WF_ABI_VERSION 2
 
 enum { WF_P_TYPE = 0, WF_P_FUEL = 1, WF_P_HEAT = 2, WF_P_AGENT = 3 };
 enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4,
@@ -62,6 +63,14 @@ enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4,
        WF_DIRT_BURNING = 5,     /* reference: type dirt, member of burning_cells, fire_mobility inf */
        WF_BURNT_BLOCKED = 6 };  /* reference: type burnt, fire_mobility inf (dig() turns it into WF_DIRT) */
 #define WF_HEAT_FORCED 25
+#define WF_HEAT_IGNITED 24   /* wind_mode != 0 only: plane 2 of a cell that accumulated heat ignited */
+
+/* Wind (environment.py:187-193, 260-287).  wf_env.wind = (wx+1) | (wy+1) << 2 | speed index << 4: the wind vector
+ * (wx, wy) in {-1,0,1}^2 and an index into wf_params.wind_speed[]. */
+#define WF_WIND_CODE(wx, wy, si) ((unsigned)((wx) + 1) | (unsigned)((wy) + 1) << 2 | (unsigned)(si) << 4)
+enum { WF_WIND_CALM = 0,     /* wind vector (0,0) for every environment: the integer rule (ignite_count)          */
+       WF_WIND_FIXED = 1,    /* METADATA['wind'] = [speed, (wx, wy)]: every reset writes wf_params.wind_code        */
+       WF_WIND_RANDOM = 2 }; /* METADATA['wind'] = "random" (environment.py:188-190): every reset draws the code    */
 
 /* wf_env.flags */
 enum {
@@ -79,7 +88,7 @@ enum {
 typedef struct wf_env {
     uint16_t x, y;       /* agent position                                   */
     uint16_t flags;      /* WF_F_*                                           */
-    uint16_t reserved;
+    uint16_t wind;       /* WF_WIND_CODE of this environment (wind_mode != 0)  */
     uint32_t episode;    /* resets seen by this environment (keys the stream) */
     uint32_t tick;       /* update() calls since the last reset               */
 } wf_env;
@@ -101,6 +110,16 @@ typedef struct wf_params {
                                 * counter-based stream (same law; a river through the fire cell is redrawn)  */
     uint64_t seed;             /* stream seed for auto_reset                            */
     uint64_t env_id0;          /* global id of env 0 of this context (multi-GPU shards) */
+    /* Wind with a direction (fixed at wf_create: WF_WIND_CALM cannot be switched to or from later).  The heat addend
+     * then depends on the direction burning cell -> heated cell, wind_speed * heat * (angle + 1)^-1
+     * (environment.py:260-287), a cell ignites when the float64 sum of its addends exceeds `threshold`, and the
+     * state gains a per-direction count of addends for every grass cell (wf_wind_counts_*); plane 2 then only
+     * records how a cell was ignited (0 / WF_HEAT_FORCED / WF_HEAT_IGNITED).  Served by the thread-per-cell
+     * kernel family for every grid shape. */
+    int32_t wind_mode;         /* WF_WIND_*                                             */
+    int32_t wind_code;         /* WF_WIND_FIXED: the code of every environment          */
+    double  wind_speed[4];     /* speeds a code's index selects; {0, 0.7, 0.85} for "random" (environment.py:189) */
+    double  heat, threshold;   /* grass['heat'], grass['threshold'] (utility.py:98,100): 0.3, 3 */
 } wf_params;
 
 typedef enum wf_status {
@@ -131,6 +150,13 @@ int wf_set_stream(wf_ctx *ctx, void *hip_stream);
  * replaces: direct numpy access to World.env (environment.py:38-50) */
 int wf_upload(wf_ctx *ctx, const int8_t *planes, const wf_env *envs);
 int wf_download(wf_ctx *ctx, int8_t *planes, wf_env *envs);
+
+/* Wind only (WF_ERR_UNSUPPORTED otherwise): counts uint8 (batch, H, W, 4) = how many heat addends a GRASS cell has
+ * received per direction k of the vector heated cell - burning cell, k = 0 (0,-1), 1 (0,+1), 2 (+1,0), 3 (-1,0) (the
+ * order of _direction_to_coords, environment.py:163-171).  The reference's temp layer is the float64 sum of those
+ * addends (environment.py:290).  Download reports zero for every cell that is not grass. */
+int wf_wind_counts_upload(wf_ctx *ctx, const uint8_t *counts);
+int wf_wind_counts_download(wf_ctx *ctx, uint8_t *counts);
 
 /* World.reset() (environment.py:186-212) for envs with mask[i] != 0 (NULL = all), spawn
  * drawn from the counter-based stream keyed by (seed, env_id0 + i, episode). */

@@ -36,14 +36,18 @@ def _envs(ge):
 def test_hip_reproduces_reference(wf, path):
     ep = Episodes(path)
     md = {"allow_dig_toggle": True, "n_actions": 5} if "toggle" in path else None     # constants.py:46 as the generator set it
+    if ep.wind:
+        md = {"wind": "random"}                                                       # constants.py:39
     env = wf.BatchedForestFire(ep.B, size=ep.size, metadata=md)
-    env.upload(ep.init_planes, ep.init_envs)
+    env.upload(ep.init_planes, ep.init_envs, counts=np.zeros(ep.init_planes.shape, np.uint8) if ep.wind else None)
     n_contained = 0
     for t in range(ep.T):
         actions, _ = ep.actions_at(t)
         obs, reward, done, _ = env.step(actions)
         planes, envs = env.download()
         live = ep.check_step(t, planes, envs, reward, done.astype(np.uint8), obs, what="hip")
+        if ep.wind:
+            ep.check_temp(t, planes, env.download_counts(), what="hip")
         n_contained += int((reward[live] == 1000.0).sum())
     if "circle" in path:
         assert n_contained > 0
@@ -80,6 +84,81 @@ def test_step_matches_oracle_random_actions(wf, W, H):
         n_done = int(do.sum())
     assert n_done > B // 4, "episodes should finish within the horizon"
     env.close()
+
+
+# wind with a direction (environment.py:187-193, 260-287): "random" draws speed and vector per episode, a fixed
+# [speed, (wx, wy)] gives every episode the same; per-direction heat counts ride along with the planes
+@pytest.mark.parametrize("W,H,wind,auto", [(14, 14, "random", True), (10, 10, "random", False), (14, 14, [0.85, (1, -1)], False),
+                                           (24, 16, "random", False), (13, 11, [0.7, (0, 1)], True), (64, 40, "random", False)])
+def test_wind_step_and_reset_match_oracle(wf, W, H, wind, auto):
+    from tests.golden_util import WIND_SPEEDS
+    B, T = 384, 150
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(6, 30), ignite_ppm=8000, auto_reset=auto,
+                               metadata={"wind": wind})
+    assert "cells" in env.kernel_name and env.containment
+    if wind == "random":
+        op = O.default_params(fuel_lo=6, fuel_hi=30, ignite_ppm=8000, wind_mode=2, wind_speeds=WIND_SPEEDS + [0.0])
+    else:
+        op = O.default_params(fuel_lo=6, fuel_hi=30, ignite_ppm=8000, wind_mode=1, wind_code=O.wind_code(*wind[1], 0),
+                              wind_speeds=[wind[0], 0.0, 0.0, 0.0])
+    env.reset(seed=77)
+    planes, envs = O.new_state(B, H, W)
+    counts = np.zeros(planes.shape, np.uint8)
+    O.reset(planes, envs, seed=77, params=op, counts=counts)
+    gp, ge = env.download()
+    np.testing.assert_array_equal(gp, planes, err_msg="reset planes")
+    np.testing.assert_array_equal(_envs(ge), envs, err_msg="reset envs")
+    if wind == "random":
+        assert len(set(envs["wind"].tolist())) == 27          # every speed x vector is drawn
+    rng = np.random.default_rng(W * 100 + H)
+    n_done = n_ign = 0
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        obs, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op, counts=counts)
+        if auto and stopped.any():
+            O.reset(planes, envs, seed=5, mask=stopped, params=op, counts=counts)
+            ro[stopped], do[stopped] = 0.0, 0
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(env.download_counts(), counts, err_msg=f"counts t={t}")
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        n_done += int(do.sum())
+        n_ign += int((planes[..., 2] == O.HEAT_IGNITED).sum())
+    assert n_done > B // 4 and n_ign > 1000
+    env.close()
+
+
+def test_wind_adapter_draws_like_the_reference(wf):
+    """METADATA['wind'] = "random" through the single-environment adapter: a seeded reset draws the wind speed from
+    numpy's stream and the vector from Python's, before the spawn point, as World.reset does (environment.py:188-190);
+    the episode then replays the reference's, and World.env shows the reference's temperatures."""
+    import random
+    for size in (10, 14):
+        ep = Episodes([f for f in fixture_files(size) if f.endswith("_wind.npz")][0])
+        sim = wf.ForestFire(size=size, metadata={"wind": "random"})
+        for i in (0, 3, 6, 12, 15):                            # no-op episodes of the generator (ep % 3 == 0) with default fuel (ep % 5 != 4)
+            seed = int(ep.d["seeds"][i])
+            np.random.seed(seed)
+            random.seed(seed)
+            sim.reset()
+            assert (sim.W.wind_speed, *sim.W.wind_vector) == tuple(ep.d["wind"][i]), (size, i)
+            assert (sim.W.agents[0].x, sim.W.agents[0].y) == tuple(ep.d["init_agent"][i, :2])
+            lo = int(ep.ep_start[i])
+            for t in range(int(ep.lengths[i])):
+                state, reward, done, _ = sim.step(" ")
+                np.testing.assert_array_equal(state, ep.d["obs"][lo + t].astype(np.float64))
+                assert reward == ep.d["reward"][lo + t] and done == bool(ep.d["done"][lo + t])
+                if t % 16 == 0:
+                    temp = sim.W.env[:, :, sim.layer["temp"]].T
+                    known = ~np.isnan(temp)
+                    np.testing.assert_allclose(temp[known], ep.d["temp"][lo + t][known], rtol=0, atol=2e-6)
+            assert done
+        sim.close()
 
 
 # big-grid families: row-strip tiles with LDS halo masks (W % 4 == 0, W <= 256) and the generic

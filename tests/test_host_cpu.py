@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.wf_abi_version() == 1
+    assert lib.wf_abi_version() == 2
     assert lib.wf_strerror(-3).decode().startswith("no usable HIP device")
 
 
@@ -45,7 +45,32 @@ def test_default_params_match_reference_constants():
     assert (p.ignite_count, p.allow_dig_toggle, p.containment, p.auto_reset) == (19, 0, 1, 0)
     assert (p.death_penalty, p.contained_bonus, p.default_reward) == (-1000.0, 1000.0, -1.0)
     assert (p.fuel_lo, p.fuel_hi, p.ignite_ppm) == (20, 20, 0)
-    assert ctypes.sizeof(N.Params) == 72 and N.ENV_DTYPE.itemsize == 16
+    assert (p.wind_mode, p.wind_code, list(p.wind_speed)[:3]) == (N.WIND_CALM, N.wind_code(0, 0, 0), [0, 0.7, 0.85])   # constants.py:39, environment.py:189
+    assert (p.heat, p.threshold) == (0.3, 3.0)                    # utility.py:98,100
+    assert ctypes.sizeof(N.Params) == 128 and N.ENV_DTYPE.itemsize == 16
+
+
+def test_no_wind_brings_a_heat_sum_near_the_threshold():
+    """Wind with a direction (environment.py:187-193, 260-287): a grass cell's temperature is a sum of up to four
+    different addends, which the reference accumulates in the iteration order of its burning set and the kernel
+    (wf_step_cells<true>) and the oracle in theirs.  All orders decide `temp > threshold` alike as long as no
+    combination of counts puts the exact sum within rounding distance of the threshold.  Enumerate every combination
+    a cell can hold before it ignites, for every wind "random" can draw: the closest one stays 1.9e-5 away - eleven
+    orders of magnitude more than 250 float64 roundings."""
+    import math
+    heat, thr = 0.3, 3.0
+    worst = np.inf
+    for speed in (0.7, 0.85):
+        for wx in (-1, 0, 1):
+            for wy in (-1, 0, 1):
+                c = [speed * heat * (abs(math.atan2(wx * cy - wy * cx, wx * cx + wy * cy)) + 1) ** (-1)
+                     for cx, cy in ((0, -1), (0, 1), (1, 0), (-1, 0))]
+                n = [np.arange(int(thr / v) + 2, dtype=np.float64) for v in c]      # beyond that one direction alone ignites
+                s = (n[0][:, None, None, None] * c[0] + n[1][None, :, None, None] * c[1]) \
+                    + (n[2][None, None, :, None] * c[2] + n[3][None, None, None, :] * c[3])
+                s = s[s < thr + max(c)]                                              # sums a cell can reach
+                worst = min(worst, float(np.abs(s - thr).min()))
+    assert 1.8e-5 < worst < 2.0e-5, worst
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-device error path")

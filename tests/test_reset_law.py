@@ -168,3 +168,21 @@ def test_device_reset_laws_match_the_reference(size):
         full[i] = w
     check_rivers(full, size)
     env.close()
+
+
+def test_oracle_wind_law_is_the_reference_draw():
+    """METADATA['wind'] = "random" (environment.py:188-190): speed = np.random.choice([0, 0.7, 0.85]) and the vector
+    (r.randint(-1, 1), r.randint(-1, 1)) - three independent uniform draws, 27 equally likely winds per episode.
+    (The device reset equals the oracle's bit for bit: test_wind_step_and_reset_match_oracle.)"""
+    from scipy.stats import chisquare
+    B = 54000
+    planes, envs = O.new_state(B, 10, 10)
+    O.reset(planes, envs, seed=99, params=O.default_params(wind_mode=2))
+    code = envs["wind"].astype(int)
+    wx, wy, si = code & 3, (code >> 2) & 3, code >> 4
+    assert wx.max() == 2 and wy.max() == 2 and si.max() == 2
+    cells = np.bincount(si * 9 + wy * 3 + wx, minlength=27)
+    assert chisquare(cells).pvalue > P_MIN, cells
+    # and a new episode draws anew
+    O.reset(planes, envs, seed=99, params=O.default_params(wind_mode=2))
+    assert 0.9 < (envs["wind"] != code).mean() / (26 / 27) < 1.1

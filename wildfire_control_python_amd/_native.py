@@ -20,11 +20,13 @@ assert ENV_DTYPE.itemsize == 16
 P_TYPE, P_FUEL, P_HEAT, P_AGENT = 0, 1, 2, 3
 GRASS, FIRE, BURNT, DIRT, WATER = 0, 1, 2, 3, 4
 HEAT_FORCED = 25
+HEAT_IGNITED = 24          # wind with a direction: plane 2 of a cell ignited by accumulated heat
+WIND_CALM, WIND_FIXED, WIND_RANDOM = 0, 1, 2
 F_ALIVE, F_VISIBLE, F_DIGGING, F_DEAD = 1, 2, 4, 8
 F_RUNNING, F_BORDER, F_CONTAINED, F_REACH_VALID, F_REACH_ROWS = 16, 32, 64, 128, 256
 
 WF_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Params(ctypes.Structure):
@@ -34,7 +36,17 @@ class Params(ctypes.Structure):
                 ("default_reward", ctypes.c_double),
                 ("fuel_lo", ctypes.c_int32), ("fuel_hi", ctypes.c_int32),
                 ("ignite_ppm", ctypes.c_uint32), ("make_rivers", ctypes.c_int32),
-                ("seed", ctypes.c_uint64), ("env_id0", ctypes.c_uint64)]
+                ("seed", ctypes.c_uint64), ("env_id0", ctypes.c_uint64),
+                ("wind_mode", ctypes.c_int32), ("wind_code", ctypes.c_int32),
+                ("wind_speed", ctypes.c_double * 4),
+                ("heat", ctypes.c_double), ("threshold", ctypes.c_double)]
+
+
+def wind_code(wx, wy, speed_index=0):
+    """WF_WIND_CODE of include/wildfire.h: wind vector (wx, wy) in {-1,0,1}^2 + index into Params.wind_speed."""
+    if wx not in (-1, 0, 1) or wy not in (-1, 0, 1) or not 0 <= speed_index <= 3:
+        raise ValueError("wind vector components must be -1, 0 or 1 (environment.py:190)")
+    return (int(wx) + 1) | (int(wy) + 1) << 2 | int(speed_index) << 4
 
 
 class WildfireError(RuntimeError):
@@ -57,6 +69,8 @@ SYMBOLS = [
     ("wf_set_stream", _i, [_vp, _vp]),
     ("wf_upload", _i, [_vp, _vp, _vp]),
     ("wf_download", _i, [_vp, _vp, _vp]),
+    ("wf_wind_counts_upload", _i, [_vp, _vp]),
+    ("wf_wind_counts_download", _i, [_vp, _vp]),
     ("wf_reset", _i, [_vp, _vp, _u64]),
     ("wf_reset_device", _i, [_vp, _vp, _u64]),
     ("wf_step", _i, [_vp, _vp, _i, _u64, _vp, _vp]),

@@ -55,15 +55,29 @@ class BatchedForestFire:
         self.seed = int(seed)
         self._reset_count = 0
 
-        wind = self.METADATA["wind"]
-        if wind == "random" or tuple(wind[1]) != (0, 0):
-            # environment.py:188-190: direction-dependent addends summed in Python set order;
-            # the reference itself is not bit-reproducible there - out of parity scope.
-            raise NotImplementedError("only wind vector (0, 0) has an exact integer restatement")
-        self.wind_speed, self.wind_vector = wind[0], tuple(wind[1])
-
+        # World.reset, environment.py:187-193.  Wind vector (0,0): every heat addend is the same quantum and the rule
+        # is an integer count (ignite_count).  A vector with a direction - fixed, or drawn per episode with "random" -
+        # makes the addend depend on the direction burning cell -> neighbour: the state gains per-direction counts
+        # (upload/download_counts) and the thread-per-cell kernels serve every shape.
         p = N.default_params()
-        p.ignite_count = ignite_count(self.wind_speed)
+        wind = self.METADATA["wind"]
+        self.wind_random = wind == "random"
+        if self.wind_random:
+            p.wind_mode = N.WIND_RANDOM
+            self.wind_speeds = (0, 0.7, 0.85)                                  # environment.py:189
+            self.wind_speed, self.wind_vector = None, None                     # per environment: see winds()
+        else:
+            self.wind_speed, self.wind_vector = wind[0], tuple(int(v) for v in wind[1])
+            self.wind_speeds = (self.wind_speed, 0.0, 0.0)
+            if self.wind_vector != (0, 0):
+                p.wind_mode = N.WIND_FIXED
+                p.wind_code = N.wind_code(*self.wind_vector, 0)
+        self.wind_mode = int(p.wind_mode)
+        for i, v in enumerate(self.wind_speeds):
+            p.wind_speed[i] = float(v)
+        p.heat, p.threshold = float(grass["heat"]), float(grass["threshold"])
+        if self.wind_mode == N.WIND_CALM:
+            p.ignite_count = ignite_count(self.wind_speed)
         p.allow_dig_toggle = int(bool(self.METADATA["allow_dig_toggle"]))
         # containment test of get_reward: built for the one-wave grid family; None = "if available"
         p.containment = 1 if containment is None else int(bool(containment))
@@ -133,10 +147,15 @@ class BatchedForestFire:
         return self._lib.wf_envs_device(self._h)
 
     # ------------------------------------------------------------- state exchange
-    def upload(self, planes=None, envs=None):
+    def upload(self, planes=None, envs=None, counts=None):
         """Replace device state.  planes int8 (batch,H,W,4); envs _native.ENV_DTYPE (batch,).
         When envs is omitted it is derived from the planes the way Agent.__init__ does
-        (environment.py:103-109): the agent is where the agent_pos plane says."""
+        (environment.py:103-109): the agent is where the agent_pos plane says.
+        counts (wind with a direction only): uint8 (batch,H,W,4) heat addends received per direction."""
+        if counts is not None:
+            counts = np.ascontiguousarray(counts, dtype=np.uint8)
+            assert counts.shape == (self.batch, self.height, self.width, 4), counts.shape
+            self._ck(self._lib.wf_wind_counts_upload(self._h, N.ptr(counts)), "wf_wind_counts_upload")
         if planes is not None:
             planes = np.ascontiguousarray(planes, dtype=np.int8)
             assert planes.shape == (self.batch, self.height, self.width, 4), planes.shape
@@ -152,6 +171,35 @@ class BatchedForestFire:
         envs = np.empty(self.batch, dtype=N.ENV_DTYPE)
         self._ck(self._lib.wf_download(self._h, N.ptr(planes), N.ptr(envs)), "wf_download")
         return planes, envs
+
+    def download_counts(self):
+        """Wind with a direction: uint8 (batch,H,W,4), how many heat addends every grass cell has received from a
+        burning cell below / above / left / right of it (the vector to it pointing N / S / E / W); the reference's
+        temp layer is the sum of those addends (wind_addends())."""
+        counts = np.empty((self.batch, self.height, self.width, 4), dtype=np.uint8)
+        self._ck(self._lib.wf_wind_counts_download(self._h, N.ptr(counts)), "wf_wind_counts_download")
+        return counts
+
+    def winds(self, envs=None):
+        """(speed float64 (batch,), vector int (batch, 2)) = World.wind_speed / wind_vector of every environment."""
+        if self.wind_mode == N.WIND_CALM:
+            return np.full(self.batch, float(self.wind_speed)), np.zeros((self.batch, 2), dtype=int)
+        code = (self.download_envs() if envs is None else envs)["wind"].astype(int)
+        speed = np.asarray(self.wind_speeds + (0.0,) * (4 - len(self.wind_speeds)))[(code >> 4) & 3]
+        return speed, np.stack([(code & 3) - 1, ((code >> 2) & 3) - 1], axis=1)
+
+    def wind_addends(self, envs=None):
+        """float64 (batch, 4): the heat a burning cell hands to its neighbour in direction N, S, E, W per tick
+        (apply_heat_from_to, environment.py:278-287)."""
+        import math
+        speed, vec = self.winds(envs)
+        out = np.empty((self.batch, 4))
+        for k, (cx, cy) in enumerate(((0, -1), (0, 1), (1, 0), (-1, 0))):
+            for b in range(self.batch):
+                wx, wy = vec[b]
+                angle = abs(math.atan2(wx * cy - wy * cx, wx * cx + wy * cy))
+                out[b, k] = speed[b] * grass["heat"] * (angle + 1) ** (-1)
+        return out
 
     def download_envs(self):
         """Only the per-environment records (16 B each): agent position, flags, episode, tick."""
@@ -185,10 +233,14 @@ class BatchedForestFire:
         self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
         return self.get_state()
 
-    def reset_host(self, spawns=None, rng=np.random):
+    def reset_host(self, spawns=None, rng=np.random, pyrng=None):
         """World.reset() built on the host and uploaded: spawn points either given
         ((batch,2) x,y) or drawn from numpy's legacy stream in the reference's own
-        order (utility.py:66-78), so a seeded run spawns where the reference does."""
+        order (utility.py:66-78), so a seeded run spawns where the reference does.
+        With wind "random" the speed comes from `rng` and the vector from `pyrng` (Python's random module by
+        default), first of all draws, as in World.reset (environment.py:188-190)."""
+        if pyrng is None:
+            import random as pyrng
         B, H, W = self.batch, self.height, self.width
         planes = np.zeros((B, H, W, 4), dtype=np.int8)
         planes[..., N.P_FUEL] = grass["fuel"]                              # reset_map :63
@@ -196,7 +248,12 @@ class BatchedForestFire:
         planes[:, fy, fx, N.P_TYPE] = N.FIRE                               # set_fire_to :233-246
         planes[:, fy, fx, N.P_HEAT] = N.HEAT_FORCED
         envs = np.zeros(B, dtype=N.ENV_DTYPE)
+        if self.wind_mode == N.WIND_FIXED:
+            envs["wind"] = N.wind_code(*self.wind_vector, 0)
         for b in range(B):
+            if self.wind_random:
+                si = list(self.wind_speeds).index(rng.choice(list(self.wind_speeds)))
+                envs[b]["wind"] = N.wind_code(pyrng.randint(-1, 1), pyrng.randint(-1, 1), si)
             if self.METADATA["make_rivers"]:
                 self._make_river(planes[b], rng)          # drawn BEFORE the spawn point, as reset_map does
                 planes[b, fy, fx, N.P_TYPE] = N.FIRE       # set_fire_to retypes the centre afterwards
@@ -205,7 +262,7 @@ class BatchedForestFire:
             planes[b, sy, sx, N.P_TYPE] = N.DIRT
             envs[b]["x"], envs[b]["y"] = sx, sy
         envs["flags"] = N.F_ALIVE | N.F_VISIBLE | N.F_DIGGING | N.F_RUNNING
-        self.upload(planes, envs)
+        self.upload(planes, envs, np.zeros(planes.shape, np.uint8) if self.wind_mode != N.WIND_CALM else None)
         self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
         return self.get_state()
 

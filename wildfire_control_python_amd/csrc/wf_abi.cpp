@@ -4,6 +4,7 @@
 // containment bitboards, staging buffers) and launches the gfx950 kernels of
 // wf_kernels.hip on the context's HIP stream.  There is NO CPU fallback: without a
 // usable HIP device wf_create fails with WF_ERR_NO_DEVICE.
+#include <math.h>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,7 @@ struct wf_ctx {
     u64 *d_halo = nullptr;            // tiled family (steps in place): masks of the rows between workgroups
     wf_env *envs = nullptr;
     u64 *reach = nullptr;
+    uint32_t *wind_cnt = nullptr;     // wind only: per-direction heat counts, one dword per cell
     // device staging for the host-buffer entry points (grown on demand)
     int8_t *d_actions = nullptr;
     double *d_reward = nullptr;
@@ -95,6 +97,14 @@ bool params_ok(const wf_params *p)
     if (p->ignite_count < 1 || p->ignite_count >= WF_HEAT_FORCED) return false;
     if (p->fuel_lo < 1 || p->fuel_hi < p->fuel_lo || p->fuel_hi > 127) return false;
     if (p->ignite_ppm > 1000000u) return false;
+    if (p->wind_mode < WF_WIND_CALM || p->wind_mode > WF_WIND_RANDOM) return false;
+    if (p->wind_mode != WF_WIND_CALM) {
+        const unsigned code = (unsigned)p->wind_code;
+        if ((code & 3u) > 2u || ((code >> 2) & 3u) > 2u || code > 63u) return false;
+        for (double v : p->wind_speed)
+            if (!(v >= 0.0) || !isfinite(v)) return false;
+        if (!(p->heat > 0.0) || !(p->threshold > 0.0) || !isfinite(p->heat) || !isfinite(p->threshold)) return false;
+    }
     return true;
 }
 
@@ -116,6 +126,7 @@ WfArgs base_args(const wf_ctx *c)
     a.reach_rows = c->fam == WF_FAM_WAVE ? c->reach + (size_t)c->batch * 4 : nullptr;
     a.step_stride = c->batch;
     a.cold = c->d_cold;
+    a.wind_cnt = c->wind_cnt;
     a.batch = c->batch;
     a.H = c->H;
     a.W = c->W;
@@ -123,7 +134,8 @@ WfArgs base_args(const wf_ctx *c)
     a.update_mask = ~0ull;
     a.ignite_count = c->p.ignite_count;
     a.hot_flags = (c->p.containment ? WF_HOT_CONTAINMENT : 0) | (c->p.auto_reset ? WF_HOT_AUTO_RESET : 0) |
-                  (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0) | (c->p.make_rivers ? WF_HOT_RIVERS : 0);
+                  (c->p.allow_dig_toggle ? WF_HOT_DIG_TOGGLE : 0) | (c->p.make_rivers ? WF_HOT_RIVERS : 0) |
+                  (c->p.wind_mode != WF_WIND_CALM ? WF_HOT_WIND : 0);
     a.group = c->knobs.group;          // experiment knob: cap on environments per wave of the single-step kernel
 #ifdef WF_WAVE_TIMING
     a.mask = static_cast<const uint8_t *>(c->dbg_timing);
@@ -175,6 +187,20 @@ int push_cold(wf_ctx *c)
     memset(&h, 0, sizeof(h));
     h.p = c->p;
     h.spawn = c->spawn;
+    if (c->p.wind_mode != WF_WIND_CALM) {
+        // the addend of apply_heat_from_to per wind and direction, in the reference's own float64 expression:
+        // angle = abs(atan2(wx*cy - wy*cx, wx*cx + wy*cy)) (environment.py:273), distance 1 (manhattan, radius 1),
+        // heat = wind_speed * cell heat * (angle + distance)^-1 (:286-287)
+        static const int dcx[4] = { 0, 0, 1, -1 }, dcy[4] = { -1, 1, 0, 0 };   // heated cell - burning cell: N, S, E, W
+        for (int si = 0; si < 4; ++si)
+            for (int v = 0; v < 16; ++v)
+                for (int k = 0; k < 4; ++k) {
+                    const double wx = (double)((v & 3) - 1), wy = (double)(((v >> 2) & 3) - 1);
+                    const double cx = dcx[k], cy = dcy[k];
+                    const double angle = fabs(atan2(wx * cy - wy * cx, wx * cx + wy * cy));
+                    h.wind_c[si][v][k] = c->p.wind_speed[si] * c->p.heat * pow(angle + 1.0, -1.0);
+                }
+    }
     HIP_TRY(c, hipMemcpy(c->d_cold, &h, sizeof(h), hipMemcpyHostToDevice));
     return WF_OK;
 }
@@ -236,6 +262,14 @@ void wf_default_params(wf_params *p)
     p->ignite_ppm = 0;
     p->seed = 0;
     p->env_id0 = 0;
+    p->wind_mode = WF_WIND_CALM;   // constants.py:39: [0.54, (0, 0)]
+    p->wind_code = WF_WIND_CODE(0, 0, 0);
+    p->wind_speed[0] = 0.0;        // environment.py:189
+    p->wind_speed[1] = 0.7;
+    p->wind_speed[2] = 0.85;
+    p->wind_speed[3] = 0.0;
+    p->heat = 0.3;                 // utility.py:98
+    p->threshold = 3.0;            // utility.py:100
 }
 
 const char *wf_strerror(int status)
@@ -261,7 +295,8 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     wf_params pp;
     if (p) pp = *p; else wf_default_params(&pp);
     if (!params_ok(&pp)) return WF_ERR_ARG;
-    const WfFamily fam = wf_pick_family(H, W);
+    // wind with a direction is served by the thread-per-cell family, whatever the shape
+    const WfFamily fam = pp.wind_mode != WF_WIND_CALM ? WF_FAM_CELLS : wf_pick_family(H, W);
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
     // the wave kernels address the planes with 32-bit byte offsets
     if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;
@@ -317,6 +352,10 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
             if ((e = hipMemsetAsync(c->d_mode, 0, (size_t)batch, c->stream)) != hipSuccess) break;
             if ((e = hipMemsetAsync(c->d_acc, 0, (size_t)batch * 16, c->stream)) != hipSuccess) break;
         }
+        if (pp.wind_mode != WF_WIND_CALM) {
+            if ((e = hipMalloc((void **)&c->wind_cnt, cells * 4)) != hipSuccess) break;
+            if ((e = hipMemsetAsync(c->wind_cnt, 0, cells * 4, c->stream)) != hipSuccess) break;
+        }
         if ((e = hipMalloc((void **)&c->envs, (size_t)batch * sizeof(wf_env))) != hipSuccess) break;
         // wave family: (batch,4) boards of the 4-cells-per-lane kernels + as much again for the rows layout
         // tiled family: u64[batch][H][4] lane masks; generic family: one byte per cell
@@ -351,7 +390,7 @@ int wf_destroy(wf_ctx *c)
         if (sd) (void)hipStreamSynchronize(sd);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_actions, c->d_reward,
-                     c->d_done, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo };
+                     c->d_done, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo, c->wind_cnt };
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -372,6 +411,8 @@ int wf_set_params(wf_ctx *c, const wf_params *p)
     if (c->fam == WF_FAM_CELLS && p->containment && (long long)c->H * c->W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
     if (p->make_rivers && !rivers_ok(c->fam, c->H, c->W)) return WF_ERR_UNSUPPORTED;
+    // the kernel family and the count plane were chosen in wf_create
+    if ((p->wind_mode != WF_WIND_CALM) != (c->p.wind_mode != WF_WIND_CALM)) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -416,6 +457,37 @@ int wf_download(wf_ctx *c, int8_t *planes, wf_env *envs)
     if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, cells * 4, hipMemcpyDeviceToHost, c->stream));
     if (envs) HIP_TRY(c, hipMemcpyAsync(envs, c->envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_wind_counts_upload(wf_ctx *c, const uint8_t *counts)
+{
+    if (!c || !counts) return WF_ERR_ARG;
+    if (!c->wind_cnt) return WF_ERR_UNSUPPORTED;
+    HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
+    HIP_TRY(c, hipMemcpyAsync(c->wind_cnt, counts, (size_t)c->batch * c->H * c->W * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WF_OK;
+}
+
+int wf_wind_counts_download(wf_ctx *c, uint8_t *counts)
+{
+    if (!c || !counts) return WF_ERR_ARG;
+    if (!c->wind_cnt) return WF_ERR_UNSUPPORTED;
+    HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
+    const size_t cells = (size_t)c->batch * c->H * c->W;
+    uint32_t *types = static_cast<uint32_t *>(malloc(cells * 4));
+    if (!types) return WF_ERR_NOMEM;
+    hipError_t e = hipMemcpyAsync(counts, c->wind_cnt, cells * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(types, c->planes, cells * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)       // only a grass cell's counts are state (a burning or burnt cell never takes heat again)
+        for (size_t i = 0; i < cells; ++i)
+            if ((types[i] & 0xffu) != (uint32_t)WF_GRASS) memset(counts + 4 * i, 0, 4);
+    free(types);
+    HIP_TRY(c, e);
     return WF_OK;
 }
 
@@ -537,6 +609,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.planes += (size_t)lo * cells;
             a.planes_out += (size_t)lo * cells;
             a.envs += lo;
+            if (a.wind_cnt) a.wind_cnt += (size_t)lo * cells;
             a.reach = c->fam == WF_FAM_TILED ? a.reach + (size_t)lo * c->H * 4
                                              : reinterpret_cast<u64 *>(reinterpret_cast<uint8_t *>(a.reach) + (size_t)lo * cells);
             a.actions = d_actions ? d_actions + off + lo : nullptr;

@@ -23,9 +23,12 @@ struct WfSpawn {
 struct WfCold {
     wf_params p;
     WfSpawn spawn;
+    // wind (wf_params.wind_mode != 0): heat addend [speed index][(wy+1)*4 + (wx+1)][direction k], computed on the host
+    // with the reference's own float64 expression (environment.py:260-287)
+    double wind_c[4][16][4];
 };
 
-enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8 };
+enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8, WF_HOT_WIND = 16 };
 // The two options that are off in the reference's default configuration (constants.py:44,46) live in separate
 // instantiations of the step kernels (template parameter RARE), so that they cost the default path neither
 // registers nor instructions.
@@ -44,6 +47,7 @@ struct WfArgs {
     const uint8_t *mask;     // reset: per-env mask or nullptr
     const WfCold *cold;      // device copy of the rarely needed parameters
     int8_t *obs;             // optional fused observation output (batch, W, H, 3) of the final state
+    uint32_t *wind_cnt;      // wind only: (batch, H*W) per-direction heat counts, one byte per direction
     int32_t batch, H, W, n_steps;
     u64 update_mask;
     u64 reset_seed;          // wf_reset: explicit seed (auto_reset uses cold->p.seed)

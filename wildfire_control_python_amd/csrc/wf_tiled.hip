@@ -46,6 +46,12 @@ __device__ __forceinline__ void reset_record(const WfArgs &a, uint32_t e, u64 se
     const uint32_t sx = (uint32_t)a.W / 2u + (int)cold->spawn.dx[r][k], sy = (uint32_t)a.H / 2u + (int)cold->spawn.dy[r][k];
     ev.x = sx | (sy << 16);
     ev.y = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING;
+    if (a.hot_flags & WF_HOT_WIND) {                                        // World.reset :187-193
+        uint32_t code = (uint32_t)cold->p.wind_code;
+        if (cold->p.wind_mode == WF_WIND_RANDOM)                            // :189-190, three uniform draws
+            code = WF_WIND_CODE((int)below(key.draw(3), 3u) - 1, (int)below(key.draw(4), 3u) - 1, below(key.draw(2), 3u));
+        ev.y |= code << 16;
+    }
     ev.z += 1;
     ev.w = 0;
     *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
@@ -95,6 +101,7 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
     ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
     have_record = false;
     uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu;
+    const uint32_t wind = ev.y & 0xffff0000u;
     if (!(fl & WF_F_RUNNING)) {
         const bool rs = (a.hot_flags & WF_HOT_AUTO_RESET) != 0;
         if (a.reward) a.reward[e] = 0.0;
@@ -164,7 +171,7 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
     if (dug) pe[(size_t)qd * 4] = (uint8_t)dugtype;
     if (fl & WF_F_VISIBLE) pe[(size_t)(ay * W + ax) * 4 + 3] = 1;
     ev.x = ax | (ay << 16);
-    ev.y = fl;
+    ev.y = fl | wind;
     have_record = true;                               // the caller writes it (after a flood, with its valid flag)
     return m;
 }
@@ -200,7 +207,7 @@ __device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, 
         fl |= WF_F_CONTAINED;                                                          // :361-367
         reward = a.contained_bonus;
     }
-    ev.y = fl;
+    ev.y = (ev.y & 0xffff0000u) | fl;
     *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
     if (a.reward) a.reward[e] = reward;
     if (a.done) a.done[e] = (fl & WF_F_RUNNING) ? 0 : 1;                               // forest_fire.py:48
@@ -684,6 +691,13 @@ __global__ __launch_bounds__(256) void wf_cells_flood(const WfArgs a, const uint
 
 // ---------------------------------------------------------------------------- generic step
 // Any grid shape: one thread per cell, neighbours read from the source planes.
+// WIND: wind with a direction (wf_params.wind_mode != 0).  The addend a burning cell hands to a neighbour depends on the
+// direction between them (environment.py:260-287), so a grass cell keeps one count per direction (a.wind_cnt, a byte
+// each) and ignites when the float64 sum of its counted addends exceeds the threshold (:293).  The reference adds in
+// the order its burning set iterates and rounds differently in the last bits; no reachable count combination brings
+// the sum closer than 1.9e-5 to the threshold for the winds "random" can draw (tests/test_host_cpu.py enumerates
+// them), so every order decides alike.
+template <bool WIND>
 __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8_t *mode, uint32_t *acc)
 {
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
@@ -700,14 +714,29 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
             if ((t & 3u) == 1u) {                                                  // burning: fire or burning dirt
                 c = (c & 0xFFFF0000u) | ((c + 0xFF01u - still(c)) & 0xFFFFu);      // reduce_fuel :297-307 (low half only)
             } else if (t == WF_GRASS) {
-                uint32_t cnt = 0;                                                  // get_neighbours :311-326
-                if (x > 0) cnt += still(se[q - 1]);
-                if (x + 1 < W) cnt += still(se[q + 1]);
-                if (y > 0) cnt += still(se[q - W]);
-                if (y + 1 < H) cnt += still(se[q + W]);
-                const uint32_t room = ign - ((c >> 16) & 0xffu);
-                const uint32_t ig = cnt >= room ? 1u : 0u;                         // apply_heat_from_to :278-294
-                c += (min(cnt, room) << 16) + ig;
+                // get_neighbours :311-326.  Direction k of the vector burning cell -> this cell: the cell below heats
+                // it northwards (k = 0), the one above southwards (1), the left one eastwards (2), the right one westwards (3)
+                const uint32_t bN = y + 1 < H ? still(se[q + W]) : 0u, bS = y > 0 ? still(se[q - W]) : 0u;
+                const uint32_t bE = x > 0 ? still(se[q - 1]) : 0u, bW = x + 1 < W ? still(se[q + 1]) : 0u;
+                uint32_t ig;
+                if (WIND) {
+                    uint32_t *pn = a.wind_cnt + (size_t)e * cells + q;
+                    const uint32_t n = *pn;
+                    const uint32_t n0 = min((n & 0xffu) + bN, 255u), n1 = min(((n >> 8) & 0xffu) + bS, 255u);
+                    const uint32_t n2 = min(((n >> 16) & 0xffu) + bE, 255u), n3 = min((n >> 24) + bW, 255u);
+                    if (bN | bS | bE | bW) *pn = n0 | (n1 << 8) | (n2 << 16) | (n3 << 24);
+                    const uint32_t code = a.envs[e].wind;
+                    const double *wc = a.cold->wind_c[(code >> 4) & 3u][code & 15u];
+                    const double temp = (double)n0 * wc[0] + (double)n1 * wc[1] + (double)n2 * wc[2] + (double)n3 * wc[3];
+                    ig = ((bN | bS | bE | bW) && temp > a.cold->p.threshold) ? 1u : 0u;   // apply_heat_from_to :278-294
+                    if (ig) c |= (uint32_t)WF_HEAT_IGNITED << 16;
+                    c += ig;
+                } else {
+                    const uint32_t cnt = bN + bS + bE + bW;
+                    const uint32_t room = ign - ((c >> 16) & 0xffu);
+                    ig = cnt >= room ? 1u : 0u;                                    // apply_heat_from_to :278-294
+                    c += (min(cnt, room) << 16) + ig;
+                }
                 if (ig && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) atomicOr(&acc[4 * e], 2u);
             }
         }
@@ -775,6 +804,7 @@ __global__ __launch_bounds__(256) void wf_big_reset_cells(const WfArgs a, const 
         for (uint32_t q = q0 + threadIdx.x; q < q1; q += 256u) {
             const uint32_t x = q % W, y = q / W;
             pe[q] = reset_cell(L, key, q, x, y, rivers ? (uint32_t)river_x[y] : 0xffffu, border_fire);
+            if (a.wind_cnt) a.wind_cnt[(size_t)e * cells + q] = 0;        // a fresh grid has received no heat
         }
         if (__ballot(border_fire) && __lane_id() == 0)
             atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
@@ -837,7 +867,8 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     const size_t total = (size_t)a.batch * a.H * a.W;
     size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(wf_step_cells, dim3((unsigned)blocks), dim3(256), 0, s, a, mode, acc);
+    if (a.hot_flags & WF_HOT_WIND) hipLaunchKernelGGL(wf_step_cells<true>, dim3((unsigned)blocks), dim3(256), 0, s, a, mode, acc);
+    else hipLaunchKernelGGL(wf_step_cells<false>, dim3((unsigned)blocks), dim3(256), 0, s, a, mode, acc);
     hipLaunchKernelGGL(wf_big_post, dim3(eb), dim3(256), 0, s, a, mode, acc);
     return hipGetLastError();
 }

@@ -62,8 +62,9 @@ class World:
         self._sim = sim
         self.WIDTH, self.HEIGHT = sim.width, sim.height
         self.DEPTH = 3                                           # get_state().shape[2], :181
-        self.wind_speed = sim._b.wind_speed
+        self.wind_speed = sim._b.wind_speed                      # per episode with wind "random": set by _refresh
         self.wind_vector = sim._b.wind_vector
+        self._counts, self._addends = None, None
         self._last_reward = 0
         self._planes = np.zeros((self.HEIGHT, self.WIDTH, 4), dtype=np.int8)
         self._env = np.zeros((), dtype=N.ENV_DTYPE)
@@ -74,6 +75,11 @@ class World:
     def _refresh(self):
         planes, envs = self._sim._b.download()
         self._planes, self._env = planes[0], envs[0]
+        b = self._sim._b
+        if b.wind_mode != N.WIND_CALM:                           # environment.py:187-193
+            speed, vec = b.winds(envs)
+            self.wind_speed, self.wind_vector = float(speed[0]), (int(vec[0][0]), int(vec[0][1]))
+            self._counts, self._addends = b.download_counts()[0], b.wind_addends(envs)[0]
         fl = int(self._env["flags"])
         self.RUNNING = bool(fl & N.F_RUNNING)
         self.fire_at_border = bool(fl & N.F_BORDER)
@@ -110,8 +116,7 @@ class World:
         out = np.zeros((self.WIDTH, self.HEIGHT, 9))
         out[:, :, layer["type"]] = t
         out[:, :, layer["gray"]] = _GRAY[code]
-        out[:, :, layer["temp"]] = np.vectorize(lambda n: temp_from_count(n, self.wind_speed))(
-            p[:, :, N.P_HEAT].T)
+        out[:, :, layer["temp"]] = self._temp().T
         out[:, :, layer["heat"]] = grass["heat"]
         out[:, :, layer["fuel"]] = p[:, :, N.P_FUEL].T
         out[:, :, layer["threshold"]] = grass["threshold"]
@@ -120,6 +125,19 @@ class World:
         out[:, :, layer["agent_mobility"]] = np.where(code == N.WATER, np.inf, 1.0)
         out.setflags(write=False)
         return out
+
+    def _temp(self):
+        """float64 (H, W): the temp layer.  Wind vector (0,0): the running sum of equal addends the heat plane counts.
+        Wind with a direction: the sum of the counted per-direction addends of a grass cell; threshold + 1 where
+        set_fire_to forced it (environment.py:236-237); nan for a cell that accumulated heat ignited (the build
+        keeps no temperature for a cell that can never take heat again)."""
+        heat = self._planes[:, :, N.P_HEAT]
+        if self._counts is None:
+            return np.vectorize(lambda n: temp_from_count(n, self.wind_speed))(heat)
+        t = (self._counts.astype(np.float64) * self._addends).sum(axis=-1)
+        t[heat == N.HEAT_FORCED] = grass["threshold"] + 1
+        t[heat == N.HEAT_IGNITED] = np.nan
+        return t
 
     def inbounds(self, x, y):                                   # environment.py:225-226
         return 0 <= x < self.WIDTH and 0 <= y < self.HEIGHT
@@ -157,7 +175,7 @@ class World:
         code, fuel, heat, _ = (int(v) for v in self._planes[y, x])
         here = any((a.x, a.y) == (x, y) for a in self.agents[:1])
         lines = [("\n[Color] Grayscale:", _GRAY[code], "Ascii:", _ASCII[code]),
-                 ("[Temperature] ", temp_from_count(heat, self.wind_speed)),
+                 ("[Temperature] ", float(self._temp()[y, x])),
                  ("[Heat Power] ", grass["heat"]),
                  ("[Fuel Level] ", float(fuel)),
                  ("[Ignition Threshold], ", float(grass["threshold"])),
