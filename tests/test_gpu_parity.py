@@ -88,11 +88,13 @@ def test_step_matches_oracle_random_actions(wf, W, H):
 
 # wind with a direction (environment.py:187-193, 260-287): "random" draws speed and vector per episode, a fixed
 # [speed, (wx, wy)] gives every episode the same; per-direction heat counts ride along with the planes
-@pytest.mark.parametrize("W,H,wind,auto", [(14, 14, "random", True), (10, 10, "random", False), (14, 14, [0.85, (1, -1)], False),
-                                           (24, 16, "random", False), (13, 11, [0.7, (0, 1)], True), (64, 40, "random", False)])
-def test_wind_step_and_reset_match_oracle(wf, W, H, wind, auto):
+@pytest.mark.parametrize("W,H,wind,auto,B", [(14, 14, "random", True, 384), (10, 10, "random", False, 384), (14, 14, [0.85, (1, -1)], False, 384),
+                                             (24, 16, "random", False, 384), (13, 11, [0.7, (0, 1)], True, 384),
+                                             (64, 40, "random", False, 96),        # few big grids: thread-per-cell sequence
+                                             (42, 30, "random", True, 512)])       # a workgroup per environment
+def test_wind_step_and_reset_match_oracle(wf, W, H, wind, auto, B):
     from tests.golden_util import WIND_SPEEDS
-    B, T = 384, 150
+    T = 150
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(6, 30), ignite_ppm=8000, auto_reset=auto,
                                metadata={"wind": wind})
     assert "cells" in env.kernel_name and env.containment
@@ -108,7 +110,7 @@ def test_wind_step_and_reset_match_oracle(wf, W, H, wind, auto):
     gp, ge = env.download()
     np.testing.assert_array_equal(gp, planes, err_msg="reset planes")
     np.testing.assert_array_equal(_envs(ge), envs, err_msg="reset envs")
-    if wind == "random":
+    if wind == "random" and B >= 384:
         assert len(set(envs["wind"].tolist())) == 27          # every speed x vector is drawn
     rng = np.random.default_rng(W * 100 + H)
     n_done = n_ign = 0
@@ -164,15 +166,25 @@ def test_wind_adapter_draws_like_the_reference(wf):
 # big-grid families: row-strip tiles with LDS halo masks (W % 4 == 0, W <= 256) and the generic
 # thread-per-cell kernel (any other shape).
 BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70, 6), (256, 256, 3),
-              (11, 11, 128), (13, 10, 128), (30, 23, 48), (260, 9, 8)]
+              (11, 11, 128), (13, 10, 128), (30, 23, 48), (260, 9, 8),
+              # generic family: a wave per environment (up to 1 024 cells), a workgroup per environment (more cells, 512+
+              # environments), the thread-per-cell sequence (few huge grids, or WF_CELLS_LEGACY=1: marked by a negative B)
+              (50, 42, 520), (11, 11, -128), (30, 23, -48), (15, 15, 700)]
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)
-def test_big_grid_step_matches_oracle(wf, W, H, B):
+def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
     T = 70
+    if B < 0:
+        monkeypatch.setenv("WF_CELLS_LEGACY", "1")
+        B = -B
+    auto = W in (24, 15, 50) or (W == 30 and B == 48)
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
-                               auto_reset=(W == 24))
+                               auto_reset=auto)
     assert "tiled" in env.kernel_name or "cells" in env.kernel_name
+    if "cells" in env.kernel_name:
+        legacy = "WF_CELLS_LEGACY" in __import__("os").environ or (W * H > 1024 and B < 512)
+        assert env.step_kernel == ("wf_step_cells" if legacy else "wf_step_env")
     assert env.containment                                       # both big-grid families test containment
     env.reset(seed=123)
     op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=int(env.containment))
@@ -187,7 +199,7 @@ def test_big_grid_step_matches_oracle(wf, W, H, B):
         obs, r, d, _ = env.step(a)
         stopped = (envs["flags"] & O.F_RUNNING) == 0
         ro, do = O.step(planes, envs, a, op)
-        if W == 24 and stopped.any():      # auto-reset shape
+        if auto and stopped.any():         # auto-reset shapes
             O.reset(planes, envs, seed=5, mask=stopped, params=op)
             ro[stopped], do[stopped] = 0.0, 0
         gp, ge = env.download()

@@ -223,6 +223,14 @@ bool multi_rows_call(const wf_ctx *c, int n_steps)
     return wf_multi_step_in_rows(c->fam, probe, c->knobs, c->num_cus);
 }
 
+// The same question for a batch that is not split (experiment knob WF_MULTI_SMALL)
+bool multi_rows_whole(const wf_ctx *c, int n_steps)
+{
+    WfArgs probe = base_args(c);
+    probe.n_steps = n_steps;
+    return wf_multi_step_in_rows(c->fam, probe, c->knobs, c->num_cus);
+}
+
 int ensure_staging(wf_ctx *c, int n_steps)
 {
     if (n_steps <= c->staged_steps) return WF_OK;
@@ -532,7 +540,8 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
         // kernel there (4.2e11 cell-updates/s at 65 536 x 14x14), which serves small, launch-bound batches.
         // The verdict is reached ONCE, from the shape of the whole call, and handed to every part launch
         // (WfKnobs::multi_rows): a ragged last part must not fall back to another kernel on its own.
-        const bool in_kernel = n_steps > 1 && splits(c, 1) && multi_rows_call(c, n_steps);
+        const bool sp = splits(c, 1);
+        const bool in_kernel = n_steps > 1 && (sp ? multi_rows_call(c, n_steps) : (c->knobs.multi_small && multi_rows_whole(c, n_steps)));
         WfKnobs kn = c->knobs;
         kn.multi_rows = in_kernel ? 1 : 0;
         const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
@@ -624,7 +633,8 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.obs = fused_obs ? d_obs + (size_t)lo * cells * 3 : nullptr;
             u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H) * 8 : nullptr;
             hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
-            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 4, halo, c->p.seed, si));
+            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 4, halo, c->p.seed, si,
+                                          c->fam == WF_FAM_CELLS && wf_cells_per_env_kernel(c->batch, c->H, c->W, c->knobs)));
             if (want_obs && !fused_obs)
                 HIP_TRY(c, wf_launch_get_state(a.planes_out, d_obs + (size_t)lo * cells * 3, hi - lo, c->H, c->W, si));
         }

@@ -71,6 +71,8 @@ struct WfKnobs {
     int rows;        // WF_ROWS: keep the rows layout for group overrides beyond 16
     int no_rows;     // WF_NO_ROWS: 4-cells-per-lane group layout only
     int no_multi;    // WF_NO_MULTI: an n-step call of a large batch = n single-step launches
+    int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
+    int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
     int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop
 };
 void wf_read_knobs(WfKnobs *k);
@@ -108,9 +110,11 @@ hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, const WfKnobs &k, hipSt
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 // big-grid families (wf_tiled.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out
 // halo != nullptr (tiled family): the step runs IN PLACE (planes_out == planes); halo = u64[batch][gx][8] scratch
-hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s);
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env);
 #define WF_RIVER_MAX_H 2048       // big-grid families: rows of a grid whose river fits the reset kernel's LDS row table
 #define WF_CELLS_FLOOD_MAX 60000   // generic family: cells of a grid whose reachability byte board fits the flood kernel's LDS
+// generic family: wf_big_pre -> wf_step_env instead of the five-launch sequence (decided for the context's whole batch)
+bool wf_cells_per_env_kernel(int batch, int H, int W, const WfKnobs &k);
 int wf_tiled_groups(int H);      // workgroups of wf_step_tiled per environment
 bool wf_tiled_fused_obs(int H, int W);   // wf_step_tiled writes World.get_state() itself (a.obs != nullptr) for this shape
 // sel == nullptr: all envs; sel_value >= 0: envs with sel[e] == sel_value; sel_value < 0: envs with sel[e] != 0

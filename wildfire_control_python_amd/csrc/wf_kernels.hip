@@ -441,6 +441,8 @@ void wf_read_knobs(WfKnobs *k)
     k->rows = set("WF_ROWS");
     k->no_rows = set("WF_NO_ROWS");
     k->no_multi = set("WF_NO_MULTI");
+    k->multi_small = set("WF_MULTI_SMALL");
+    k->cells_legacy = set("WF_CELLS_LEGACY");
     k->multi_rows = 0;
 }
 
@@ -478,7 +480,7 @@ const char *wf_family_name(WfFamily f, int, int)
     switch (f) {
     case WF_FAM_WAVE: return "wf_step_rows/wf_step_group/wf_step_wave (whole grids in a wave's registers, CA core on ballot bitboards; env logic lane-parallel)";
     case WF_FAM_TILED: return "wf_step_tiled (16-row strips per wave, ballot row masks, LDS-staged strip halos)";
-    case WF_FAM_CELLS: return "wf_step_cells (generic thread-per-cell)";
+    case WF_FAM_CELLS: return "wf_step_env / wf_step_cells (generic: a wave or a workgroup per environment; thread-per-cell for a few huge grids)";
     default: return "none";
     }
 }
@@ -500,7 +502,7 @@ const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &
 {
     static thread_local char buf[64];
     if (fam == WF_FAM_TILED) return "wf_step_tiled";
-    if (fam == WF_FAM_CELLS) return "wf_step_cells";
+    if (fam == WF_FAM_CELLS) return wf_cells_per_env_kernel(a.batch, a.H, a.W, k) ? "wf_step_env" : "wf_step_cells";
     StepPlan p = { 0, -1 };
     int S = 1;
 #define X(w, h) if (a.W == w && a.H == h) { p = plan_single<w, h>(a, k, num_cus); S = HasRows<w, h>::S; }

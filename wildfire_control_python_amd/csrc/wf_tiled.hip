@@ -190,10 +190,11 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
 // ---------------------------------------------------------------------------- post
 // World.RUNNING, reward, done and the record of ONE stepped environment from its reduction words
 // (A: bit 0 any fire left, bit 1 fire at the border, bit 2 fire on a border-connected cell; healthy: grass cells).
-__device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, const uint32_t m, const uint32_t A, const uint32_t healthy)
+__device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, const uint32_t m, const uint32_t A, const uint32_t healthy,
+                                             const uint32_t extra_flags = 0)
 {
     uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
-    uint32_t fl = ev.y & 0xffffu;
+    uint32_t fl = (ev.y & 0xffffu) | extra_flags;
     const uint32_t anyfire = A & 1u, bhit = (A >> 1) & 1u, reach_hit = (A >> 2) & 1u;
     const uint32_t upd = (a.update_mask & 1ull) ? 1u : 0u;
     fl |= bhit << 5;                                                                   // set_fire_to :245-246
@@ -697,6 +698,44 @@ __global__ __launch_bounds__(256) void wf_cells_flood(const WfArgs a, const uint
 // the order its burning set iterates and rounds differently in the last bits; no reachable count combination brings
 // the sum closer than 1.9e-5 to the threshold for the winds "random" can draw (tests/test_host_cpu.py enumerates
 // them), so every order decides alike.
+// One cell's tick (forest_fire.py:85-106) from its own word `c` and its four neighbours' words (nS: the cell above,
+// nN: the one below, nE: the left one, nW: the right one - named after the direction in which they heat this cell;
+// 0 where the grid ends): returns the new word; `ig` = ignited this tick.  wc / threshold / pn: wind only (addends per
+// direction, the cell's count word).
+template <bool WIND>
+__device__ __forceinline__ uint32_t cell_tick(uint32_t c, uint32_t nN, uint32_t nS, uint32_t nE, uint32_t nW, uint32_t ign,
+                                              const double *wc, double threshold, uint32_t *pn, uint32_t &ig)
+{
+    auto still = [&](uint32_t v) -> uint32_t { return ((v & 3u) == 1u && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
+    const uint32_t t = c & 0xffu;
+    ig = 0;
+    if ((t & 3u) == 1u) {                                                  // burning: fire or burning dirt
+        c = (c & 0xFFFF0000u) | ((c + 0xFF01u - still(c)) & 0xFFFFu);      // reduce_fuel :297-307 (low half only)
+    } else if (t == WF_GRASS) {
+        // get_neighbours :311-326.  Direction k of the vector burning cell -> this cell: the cell below heats
+        // it northwards (k = 0), the one above southwards (1), the left one eastwards (2), the right one westwards (3)
+        const uint32_t bN = still(nN), bS = still(nS), bE = still(nE), bW = still(nW);
+        if (WIND) {
+            if (bN | bS | bE | bW) {
+                const uint32_t n = *pn;
+                const uint32_t n0 = min((n & 0xffu) + bN, 255u), n1 = min(((n >> 8) & 0xffu) + bS, 255u);
+                const uint32_t n2 = min(((n >> 16) & 0xffu) + bE, 255u), n3 = min((n >> 24) + bW, 255u);
+                *pn = n0 | (n1 << 8) | (n2 << 16) | (n3 << 24);
+                const double temp = (double)n0 * wc[0] + (double)n1 * wc[1] + (double)n2 * wc[2] + (double)n3 * wc[3];
+                ig = temp > threshold ? 1u : 0u;                           // apply_heat_from_to :278-294
+                if (ig) c |= (uint32_t)WF_HEAT_IGNITED << 16;
+                c += ig;
+            }
+        } else {
+            const uint32_t cnt = bN + bS + bE + bW;
+            const uint32_t room = ign - ((c >> 16) & 0xffu);
+            ig = cnt >= room ? 1u : 0u;                                    // apply_heat_from_to :278-294
+            c += (min(cnt, room) << 16) + ig;
+        }
+    }
+    return c;
+}
+
 template <bool WIND>
 __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8_t *mode, uint32_t *acc)
 {
@@ -709,36 +748,17 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
         uint32_t c = se[q];
         const uint32_t m = mode[e] & MODE_MASK;
         if (m == MODE_STEP && (a.update_mask & 1ull)) {
-            auto still = [&](uint32_t v) -> uint32_t { return ((v & 3u) == 1u && (int32_t)(int8_t)(v >> 8) > 1) ? 1u : 0u; };
-            const uint32_t t = c & 0xffu;
-            if ((t & 3u) == 1u) {                                                  // burning: fire or burning dirt
-                c = (c & 0xFFFF0000u) | ((c + 0xFF01u - still(c)) & 0xFFFFu);      // reduce_fuel :297-307 (low half only)
-            } else if (t == WF_GRASS) {
-                // get_neighbours :311-326.  Direction k of the vector burning cell -> this cell: the cell below heats
-                // it northwards (k = 0), the one above southwards (1), the left one eastwards (2), the right one westwards (3)
-                const uint32_t bN = y + 1 < H ? still(se[q + W]) : 0u, bS = y > 0 ? still(se[q - W]) : 0u;
-                const uint32_t bE = x > 0 ? still(se[q - 1]) : 0u, bW = x + 1 < W ? still(se[q + 1]) : 0u;
-                uint32_t ig;
-                if (WIND) {
-                    uint32_t *pn = a.wind_cnt + (size_t)e * cells + q;
-                    const uint32_t n = *pn;
-                    const uint32_t n0 = min((n & 0xffu) + bN, 255u), n1 = min(((n >> 8) & 0xffu) + bS, 255u);
-                    const uint32_t n2 = min(((n >> 16) & 0xffu) + bE, 255u), n3 = min((n >> 24) + bW, 255u);
-                    if (bN | bS | bE | bW) *pn = n0 | (n1 << 8) | (n2 << 16) | (n3 << 24);
-                    const uint32_t code = a.envs[e].wind;
-                    const double *wc = a.cold->wind_c[(code >> 4) & 3u][code & 15u];
-                    const double temp = (double)n0 * wc[0] + (double)n1 * wc[1] + (double)n2 * wc[2] + (double)n3 * wc[3];
-                    ig = ((bN | bS | bE | bW) && temp > a.cold->p.threshold) ? 1u : 0u;   // apply_heat_from_to :278-294
-                    if (ig) c |= (uint32_t)WF_HEAT_IGNITED << 16;
-                    c += ig;
-                } else {
-                    const uint32_t cnt = bN + bS + bE + bW;
-                    const uint32_t room = ign - ((c >> 16) & 0xffu);
-                    ig = cnt >= room ? 1u : 0u;                                    // apply_heat_from_to :278-294
-                    c += (min(cnt, room) << 16) + ig;
-                }
-                if (ig && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) atomicOr(&acc[4 * e], 2u);
+            const uint32_t code = WIND ? (uint32_t)a.envs[e].wind : 0u;
+            uint32_t ig, nN = 0, nS = 0, nE = 0, nW = 0;
+            if ((c & 0xffu) == WF_GRASS) {                                         // get_neighbours :311-326
+                if (y + 1 < H) nN = se[q + W];
+                if (y > 0) nS = se[q - W];
+                if (x > 0) nE = se[q - 1];
+                if (x + 1 < W) nW = se[q + 1];
             }
+            c = cell_tick<WIND>(c, nN, nS, nE, nW, ign, WIND ? a.cold->wind_c[(code >> 4) & 3u][code & 15u] : nullptr,
+                                WIND ? a.cold->p.threshold : 0.0, WIND ? a.wind_cnt + (size_t)e * cells + q : nullptr, ig);
+            if (ig && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) atomicOr(&acc[4 * e], 2u);
         }
         a.planes_out[(size_t)e * cells + q] = c;
         if (m == MODE_STEP) {
@@ -759,6 +779,152 @@ __global__ __launch_bounds__(256) void wf_step_cells(const WfArgs a, const uint8
                 if (t == WF_GRASS) atomicAdd(&acc[4 * e + 1], 1u);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------- generic step, one wave / workgroup per environment
+// The generic family's step behind wf_big_pre as ONE launch: NT threads own an environment (NT = 64: a wave, four
+// environments per workgroup; NT = 256: a workgroup) and do what its mode asks - the fresh grid of an auto-reset, the
+// copy of a frozen one, or [reachability flood ->] tick -> World.RUNNING / reward / done - with the reductions in
+// ballots / LDS instead of global atomics.  (The five-launch sequence above costs 340 us per 65 536 x 14x14 step,
+// three quarters of it in launches whose workgroups find nothing to do and in same-address atomics; it stays for a few
+// huge grids, where one workgroup per environment would leave the chip empty.)
+template <int NT>
+__device__ __forceinline__ void env_sync()
+{
+    if constexpr (NT == 64) {      // one wave: LDS is in order, the compiler must not move accesses across this point
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int NT, bool WIND>
+__global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t *mode, uint32_t slot_bytes)
+{
+    extern __shared__ uint8_t env_lds[];             // per environment slot: reachability byte board / river row table
+    constexpr uint32_t EPB = 256 / NT;
+    __shared__ uint32_t red[EPB][4];                 // flags, healthy, changed (flood), -
+    const uint32_t slot = threadIdx.x / NT, t = threadIdx.x % NT;
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
+    const uint32_t ign = (uint32_t)a.ignite_count;
+    uint8_t *board = env_lds + (size_t)slot * slot_bytes;
+    const WfCold *cold = a.cold;
+    for (uint32_t e = blockIdx.x * EPB + slot; e < (uint32_t)a.batch; e += gridDim.x * EPB) {
+        const uint32_t m = mode[e], mm = m & MODE_MASK;
+        const uint32_t *__restrict__ se = a.planes + (size_t)e * cells;
+        uint32_t *__restrict__ de = a.planes_out + (size_t)e * cells;
+        if (mm == MODE_RESET) {
+            // World.reset() (environment.py:186-212): the record was written by wf_big_pre (reset_record)
+            const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+            const EnvKey key(cold->p.seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
+            const ResetLaw L = reset_law(a, ev);
+            const bool rivers = cold->p.make_rivers != 0;
+            uint16_t *river_x = reinterpret_cast<uint16_t *>(board);
+            if (rivers) {
+                env_sync<NT>();
+                for (uint32_t r = t; r < H; r += NT) river_x[r] = 0xffffu;
+                env_sync<NT>();
+                if (t == 0) river_cells(key, (int)W, (int)H, [&](int x, int y) { river_x[y] = (uint16_t)x; });
+                env_sync<NT>();
+            }
+            bool border_fire = false;
+            for (uint32_t q = t; q < cells; q += NT) {
+                const uint32_t x = q % W, y = q / W;
+                de[q] = reset_cell(L, key, q, x, y, rivers ? (uint32_t)river_x[y] : 0xffffu, border_fire);
+                if (WIND) a.wind_cnt[(size_t)e * cells + q] = 0;            // a fresh grid has received no heat
+            }
+            if (__ballot(border_fire) && __lane_id() == 0)
+                atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+            if (rivers) env_sync<NT>();
+            continue;
+        }
+        if (mm != MODE_STEP) {                        // frozen after done: the grid moves to the other buffer unchanged
+            if (de != se)
+                for (uint32_t q = t; q < cells; q += NT) de[q] = se[q];
+            continue;
+        }
+        uint8_t *reach_e = reinterpret_cast<uint8_t *>(a.reach) + (size_t)e * cells;
+        uint32_t valid = 0;
+        if (m & MODE_FLOOD) {
+            // border-reachability board of this environment (see wf_cells_flood): 0 impassable, 1 passable, 3 passable + reached
+            for (uint32_t q = t; q < cells; q += NT) {
+                const uint32_t x = q % W, y = q / W;
+                const bool pass = (se[q] & 0xffu) < (uint32_t)WF_DIRT;
+                const bool edge = x == 0 || y == 0 || x == W - 1 || y == H - 1;
+                board[q] = pass ? (edge ? 3 : 1) : 0;
+            }
+            env_sync<NT>();
+            for (uint32_t it = 0; it < cells; ++it) {
+                if (t == 0) red[slot][2] = 0;
+                env_sync<NT>();
+                bool ch = false;
+                for (uint32_t q = t; q < cells; q += NT) {
+                    if (board[q] != 1) continue;
+                    const uint32_t x = q % W, y = q / W;
+                    const bool nb = (x > 0 && board[q - 1] == 3) || (x + 1 < W && board[q + 1] == 3) ||
+                                    (y > 0 && board[q - W] == 3) || (y + 1 < H && board[q + W] == 3);
+                    if (nb) { board[q] = 3; ch = true; }
+                }
+                if (ch) red[slot][2] = 1;
+                env_sync<NT>();
+                const uint32_t changed = red[slot][2];
+                env_sync<NT>();
+                if (!changed) break;
+            }
+            for (uint32_t q = t; q < cells; q += NT) {
+                uint8_t v = board[q] >> 1;
+                if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (se[q] & 0xffu) == (uint32_t)WF_DIRT_BURNING) {
+                    const uint32_t x = q % W, y = q / W;     // burning dirt: reached iff a 4-neighbour is
+                    v = ((x > 0 && board[q - 1] == 3) || (x + 1 < W && board[q + 1] == 3) ||
+                         (y > 0 && board[q - W] == 3) || (y + 1 < H && board[q + W] == 3)) ? 1 : 0;
+                }
+                reach_e[q] = v;
+            }
+            env_sync<NT>();                           // (the tick reads only its own cell's byte: written by this very thread)
+            valid = WF_F_REACH_VALID;
+        }
+        // ---- the tick, with the environment's reductions in wave-uniform registers
+        const uint32_t code = WIND ? (uint32_t)a.envs[e].wind : 0u;
+        const double *wc = WIND ? cold->wind_c[(code >> 4) & 3u][code & 15u] : nullptr;
+        const double threshold = WIND ? cold->p.threshold : 0.0;
+        const bool upd = (a.update_mask & 1ull) != 0, precheck = (m & MODE_PRECHECK) != 0;
+        uint32_t A = 0, healthy = 0;
+        // every lane loads its cell, the four neighbours and the reachability byte up front (clamped addresses, the
+        // words masked where the grid ends): one memory latency per pass, and nothing in a pass depends on the last one
+#pragma unroll 2
+        for (uint32_t q0 = 0; q0 < cells; q0 += NT) {
+            const uint32_t q = q0 + t;
+            const bool in = q < cells;
+            const uint32_t qc = in ? q : cells - 1u;
+            const uint32_t y = qc / W, x = qc - y * W;
+            const bool top = y == 0, bottom = y == H - 1, left = x == 0, right = x == W - 1;
+            uint32_t c = se[qc];
+            const uint32_t vS = se[top ? qc : qc - W], vN = se[bottom ? qc : qc + W];
+            const uint32_t vE = se[left ? qc : qc - 1u], vW = se[right ? qc : qc + 1u];
+            const uint32_t rb = precheck ? (uint32_t)reach_e[qc] : 0u;
+            uint32_t ig = 0;
+            if (upd && in) c = cell_tick<WIND>(c, bottom ? 0u : vN, top ? 0u : vS, left ? 0u : vE, right ? 0u : vW, ign, wc, threshold,
+                                         WIND ? a.wind_cnt + (size_t)e * cells + qc : nullptr, ig);
+            if (in) de[q] = c;
+            const uint32_t ty = c & 0xffu;
+            const bool fire = in && (ty & 3u) == 1u;
+            if (__ballot(fire)) A |= 1u;
+            if (__ballot(in && ig && (top | bottom | left | right))) A |= 2u;               // set_fire_to :245-246
+            if (__ballot(fire && rb)) A |= 4u;                                               // environment.py:345-377
+            healthy += (uint32_t)__popcll(__ballot(in && ty == WF_GRASS));
+        }
+        if constexpr (NT != 64) {                     // four waves: combine in LDS
+            if (t == 0) { red[slot][0] = 0; red[slot][1] = 0; }
+            __syncthreads();
+            if (__lane_id() == 0) { atomicOr(&red[slot][0], A); atomicAdd(&red[slot][1], healthy); }
+            __syncthreads();
+            A = red[slot][0];
+            healthy = red[slot][1];
+            __syncthreads();
+        }
+        if (t == 0) big_post_env(a, e, m, A, healthy, valid);
     }
 }
 
@@ -833,12 +999,20 @@ hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_valu
     return launch_reset_cells(a, sel, sel_value, seed, s);
 }
 
+// Generic family: is a step served by wf_big_pre -> wf_step_env (one wave / workgroup per environment)?  Not for a few
+// huge grids, which the thread-per-cell sequence spreads over the whole chip.  WF_CELLS_LEGACY=1 forces that sequence.
+bool wf_cells_per_env_kernel(int batch, int H, int W, const WfKnobs &k)
+{
+    const long long cells = (long long)H * W;
+    return !k.cells_legacy && (cells <= 1024 || batch >= 512);
+}
+
 int wf_tiled_groups(int H) { return (H + 4 * TR - 1) / (4 * TR); }
 
 // wf_step_tiled can write the observation itself when the (x, y-run) blocks of obs are 4-byte aligned
 bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 
-hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s)
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env)
 {
     if (fam == WF_FAM_TILED) {
         // prologue (agent logic, reachability flood, outer halos) -> the in-place tick, which also writes the fresh
@@ -856,6 +1030,24 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     }
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_pre, dim3(eb), dim3(256), 0, s, a, mode);
+    if (per_env) {
+        // agent logic, then everything else of the step in one launch: a wave (grids up to 1 024 cells) or a workgroup
+        // per environment
+        const size_t cells = (size_t)a.H * a.W;
+        const bool wave = cells <= 1024;
+        const unsigned epb = wave ? 4u : 1u;
+        size_t slot = (a.hot_flags & WF_HOT_CONTAINMENT) ? cells : 0;
+        if ((a.hot_flags & WF_HOT_RIVERS) && slot < (size_t)a.H * 2) slot = (size_t)a.H * 2;
+        slot = (slot + 15) & ~(size_t)15;
+        unsigned blocks = (unsigned)((a.batch + epb - 1) / epb);
+        if (blocks > 8192) blocks = 8192;
+        const bool wind = (a.hot_flags & WF_HOT_WIND) != 0;
+        if (wave && wind) hipLaunchKernelGGL((wf_step_env<64, true>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
+        if (wave && !wind) hipLaunchKernelGGL((wf_step_env<64, false>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
+        if (!wave && wind) hipLaunchKernelGGL((wf_step_env<256, true>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
+        if (!wave && !wind) hipLaunchKernelGGL((wf_step_env<256, false>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
+        return hipGetLastError();
+    }
     if (a.hot_flags & WF_HOT_AUTO_RESET) {
         hipError_t e = launch_reset_cells(a, mode, MODE_RESET, auto_seed, s);
         if (e != hipSuccess) return e;
