@@ -169,19 +169,28 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               (11, 11, 128), (13, 10, 128), (30, 23, 48), (260, 9, 8),
               # generic family: a wave per environment (up to 1 024 cells), a workgroup per environment (more cells, 512+
               # environments), the thread-per-cell sequence (few huge grids, or WF_CELLS_LEGACY=1: marked by a negative B)
-              (50, 42, 520), (11, 11, -128), (30, 23, -48), (15, 15, 700)]
+              (50, 42, 520), (11, 11, -128), (30, 23, -48), (15, 15, 700),
+              # small grids the tiled family can serve go to the generic one (faster up to 48x48); WF_FAMILY=tiled keeps
+              # the tiled kernels covered there (marked by B + 10000)
+              (24, 24, 10096), (32, 20, 10064), (48, 48, 10024)]
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)
 def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
     T = 70
+    monkeypatch.delenv("WF_FAMILY", raising=False)
     if B < 0:
         monkeypatch.setenv("WF_CELLS_LEGACY", "1")
         B = -B
+    if B > 10000:
+        monkeypatch.setenv("WF_FAMILY", "tiled")
+        B -= 10000
+    forced_tiled = "WF_FAMILY" in __import__("os").environ
     auto = W in (24, 15, 50) or (W == 30 and B == 48)
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
                                auto_reset=auto)
     assert "tiled" in env.kernel_name or "cells" in env.kernel_name
+    assert ("tiled" in env.kernel_name) == (W % 4 == 0 and W <= 256 and (W * H > 2304 or forced_tiled))
     if "cells" in env.kernel_name:
         legacy = "WF_CELLS_LEGACY" in __import__("os").environ or (W * H > 1024 and B < 512)
         assert env.step_kernel == ("wf_step_cells" if legacy else "wf_step_env")
@@ -287,11 +296,15 @@ def _circle_actions(ge, W, H, rng):
     return a
 
 
-@pytest.mark.parametrize("W,H", [(24, 24), (32, 20), (14, 14), (13, 13), (30, 23), (11, 14)])
-def test_containment_rewards_with_circling_agents(wf, W, H):
+@pytest.mark.parametrize("W,H,family", [(24, 24, "tiled"), (32, 20, "tiled"), (14, 14, None), (13, 13, None), (30, 23, None), (11, 14, None),
+                                        (24, 24, None), (60, 44, None), (51, 47, None)])
+def test_containment_rewards_with_circling_agents(wf, monkeypatch, W, H, family):
     """Agents that dig a ring around the fire: the +1000 containment reward (get_reward's A* part,
     environment.py:345-377) must appear exactly when and where the oracle pays it - tiled family
-    (flood kernel + per-row board test) and wave family alike."""
+    (flood in the prologue + per-row board test), generic family (byte board in LDS) and wave family alike."""
+    monkeypatch.delenv("WF_FAMILY", raising=False)
+    if family:
+        monkeypatch.setenv("WF_FAMILY", family)
     B, T = 96, 150
     env = wf.BatchedForestFire(B, width=W, height=H, seed=2, containment=True)
     env.reset(seed=77)
@@ -523,11 +536,15 @@ def test_dig_toggle_matches_oracle_including_dig_on_a_burning_cell(wf, monkeypat
     if variant == "rows":
         monkeypatch.setenv("WF_GROUP", "2")
     W, H = {"tiled": (24, 16), "cells": (11, 13)}.get(variant, (10, 10))
+    if variant == "tiled":
+        monkeypatch.setenv("WF_FAMILY", "tiled")          # (a grid this small goes to the generic family by itself)
     B, T = 384, 130
     env = wf.BatchedForestFire(B, width=W, height=H, seed=21, containment=True, fuel_range=(12, 30),
                                metadata={"allow_dig_toggle": True, "n_actions": 5})
-    if variant in ("group", "rows"):
+    if variant in ("group", "rows", "tiled"):
         assert env.step_kernel.startswith("wf_step_" + variant), env.step_kernel
+    if variant == "cells":
+        assert env.step_kernel == "wf_step_env"
     env.reset(seed=21)
     op = O.default_params(allow_dig_toggle=1, containment=1, fuel_lo=12, fuel_hi=30)
     planes, envs = O.new_state(B, H, W)

@@ -304,7 +304,11 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (p) pp = *p; else wf_default_params(&pp);
     if (!params_ok(&pp)) return WF_ERR_ARG;
     // wind with a direction is served by the thread-per-cell family, whatever the shape
-    const WfFamily fam = pp.wind_mode != WF_WIND_CALM ? WF_FAM_CELLS : wf_pick_family(H, W);
+    // (WF_FAMILY=cells / tiled, experiments and tests: the generic family for a shape another family would serve, the
+    // tiled family for a small grid)
+    const char *force = getenv("WF_FAMILY");
+    WfFamily fam = (pp.wind_mode != WF_WIND_CALM || (force && !strcmp(force, "cells"))) ? WF_FAM_CELLS : wf_pick_family(H, W);
+    if (force && !strcmp(force, "tiled") && fam == WF_FAM_CELLS && pp.wind_mode == WF_WIND_CALM && wf_tiled_serves(H, W)) fam = WF_FAM_TILED;
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
     // the wave kernels address the planes with 32-bit byte offsets
     if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;

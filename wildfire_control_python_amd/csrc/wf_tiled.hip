@@ -191,9 +191,17 @@ __global__ __launch_bounds__(256) void wf_big_pre(const WfArgs a, uint8_t *mode)
 // World.RUNNING, reward, done and the record of ONE stepped environment from its reduction words
 // (A: bit 0 any fire left, bit 1 fire at the border, bit 2 fire on a border-connected cell; healthy: grass cells).
 __device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, const uint32_t m, const uint32_t A, const uint32_t healthy,
-                                             const uint32_t extra_flags = 0)
+                                             const uint32_t extra_flags, uint4 ev);
+
+__device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, const uint32_t m, const uint32_t A, const uint32_t healthy)
 {
-    uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
+    big_post_env(a, e, m, A, healthy, 0u, *reinterpret_cast<const uint4 *>(&a.envs[e]));
+}
+
+// (ev: the environment's record as it is in memory, loaded by the caller)
+__device__ __forceinline__ void big_post_env(const WfArgs &a, const uint32_t e, const uint32_t m, const uint32_t A, const uint32_t healthy,
+                                             const uint32_t extra_flags, uint4 ev)
+{
     uint32_t fl = (ev.y & 0xffffu) | extra_flags;
     const uint32_t anyfire = A & 1u, bhit = (A >> 1) & 1u, reach_hit = (A >> 2) & 1u;
     const uint32_t upd = (a.update_mask & 1ull) ? 1u : 0u;
@@ -800,24 +808,50 @@ __device__ __forceinline__ void env_sync()
     }
 }
 
-template <int NT, bool WIND>
+// STAGE: the environment's grid (and its reachability bytes) fit the slot's LDS: they are staged there by batched,
+// independent loads - one memory latency per environment instead of one per pass - and flood and tick read LDS.
+template <int NT, bool WIND, bool STAGE>
 __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t *mode, uint32_t slot_bytes)
 {
-    extern __shared__ uint8_t env_lds[];             // per environment slot: reachability byte board / river row table
+    // per environment slot: [STAGE: the grid, one word per cell] [reachability byte board | river row table]
+    extern __shared__ __attribute__((aligned(16))) uint8_t env_lds[];
     constexpr uint32_t EPB = 256 / NT;
     __shared__ uint32_t red[EPB][4];                 // flags, healthy, changed (flood), -
     const uint32_t slot = threadIdx.x / NT, t = threadIdx.x % NT;
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
     const uint32_t ign = (uint32_t)a.ignite_count;
-    uint8_t *board = env_lds + (size_t)slot * slot_bytes;
+    uint32_t *ls = reinterpret_cast<uint32_t *>(env_lds + (size_t)slot * slot_bytes);
+    uint8_t *board = env_lds + (size_t)slot * slot_bytes + (STAGE ? (size_t)cells * 4 : 0);
     const WfCold *cold = a.cold;
     for (uint32_t e = blockIdx.x * EPB + slot; e < (uint32_t)a.batch; e += gridDim.x * EPB) {
+        // everything this environment needs from memory is requested up front - mode, record, and (STAGE) the whole
+        // grid with its reachability bytes: one memory latency per environment
         const uint32_t m = mode[e], mm = m & MODE_MASK;
+        const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
         const uint32_t *__restrict__ se = a.planes + (size_t)e * cells;
         uint32_t *__restrict__ de = a.planes_out + (size_t)e * cells;
+        uint8_t *reach_e = reinterpret_cast<uint8_t *>(a.reach) + (size_t)e * cells;
+        if constexpr (STAGE) {
+            const bool want_reach = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
+            env_sync<NT>();                           // the slot's last environment is done with it
+            for (uint32_t q0 = 0; q0 < cells; q0 += NT * 8u) {
+                uint32_t v[8], r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t q = q0 + (uint32_t)k * NT + t;
+                    v[k] = q < cells ? se[q] : 0u;
+                    r[k] = (want_reach && q < cells) ? (uint32_t)reach_e[q] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t q = q0 + (uint32_t)k * NT + t;
+                    if (q < cells) { ls[q] = v[k]; if (want_reach) board[q] = (uint8_t)(r[k] << 2); }
+                }
+            }
+            env_sync<NT>();
+        }
         if (mm == MODE_RESET) {
             // World.reset() (environment.py:186-212): the record was written by wf_big_pre (reset_record)
-            const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);
             const EnvKey key(cold->p.seed, cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
             const ResetLaw L = reset_law(a, ev);
             const bool rivers = cold->p.make_rivers != 0;
@@ -845,13 +879,15 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
                 for (uint32_t q = t; q < cells; q += NT) de[q] = se[q];
             continue;
         }
-        uint8_t *reach_e = reinterpret_cast<uint8_t *>(a.reach) + (size_t)e * cells;
+        const bool upd = (a.update_mask & 1ull) != 0, precheck = (m & MODE_PRECHECK) != 0, flood = (m & MODE_FLOOD) != 0;
+        auto src = [&](uint32_t q) -> uint32_t { if constexpr (STAGE) return ls[q]; else return se[q]; };
         uint32_t valid = 0;
-        if (m & MODE_FLOOD) {
-            // border-reachability board of this environment (see wf_cells_flood): 0 impassable, 1 passable, 3 passable + reached
+        if (flood) {
+            // border-reachability board of this environment, bits 0-1: 0 impassable, 1 passable, 3 passable + reached;
+            // bit 2: the verdict the containment test reads (burning dirt: reached iff a 4-neighbour is)
             for (uint32_t q = t; q < cells; q += NT) {
                 const uint32_t x = q % W, y = q / W;
-                const bool pass = (se[q] & 0xffu) < (uint32_t)WF_DIRT;
+                const bool pass = (src(q) & 0xffu) < (uint32_t)WF_DIRT;
                 const bool edge = x == 0 || y == 0 || x == W - 1 || y == H - 1;
                 board[q] = pass ? (edge ? 3 : 1) : 0;
             }
@@ -874,25 +910,25 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
                 if (!changed) break;
             }
             for (uint32_t q = t; q < cells; q += NT) {
-                uint8_t v = board[q] >> 1;
-                if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (se[q] & 0xffu) == (uint32_t)WF_DIRT_BURNING) {
-                    const uint32_t x = q % W, y = q / W;     // burning dirt: reached iff a 4-neighbour is
-                    v = ((x > 0 && board[q - 1] == 3) || (x + 1 < W && board[q + 1] == 3) ||
-                         (y > 0 && board[q - W] == 3) || (y + 1 < H && board[q + W] == 3)) ? 1 : 0;
+                uint32_t v = (board[q] & 3u) >> 1;
+                if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (src(q) & 0xffu) == (uint32_t)WF_DIRT_BURNING) {
+                    const uint32_t x = q % W, y = q / W;
+                    v = ((x > 0 && (board[q - 1] & 3u) == 3u) || (x + 1 < W && (board[q + 1] & 3u) == 3u) ||
+                         (y > 0 && (board[q - W] & 3u) == 3u) || (y + 1 < H && (board[q + W] & 3u) == 3u)) ? 1u : 0u;
                 }
-                reach_e[q] = v;
+                reach_e[q] = (uint8_t)v;
+                board[q] |= (uint8_t)(v << 2);        // (own byte only; the neighbours' tests mask bits 0-1)
             }
-            env_sync<NT>();                           // (the tick reads only its own cell's byte: written by this very thread)
+            env_sync<NT>();
             valid = WF_F_REACH_VALID;
         }
         // ---- the tick, with the environment's reductions in wave-uniform registers
         const uint32_t code = WIND ? (uint32_t)a.envs[e].wind : 0u;
         const double *wc = WIND ? cold->wind_c[(code >> 4) & 3u][code & 15u] : nullptr;
         const double threshold = WIND ? cold->p.threshold : 0.0;
-        const bool upd = (a.update_mask & 1ull) != 0, precheck = (m & MODE_PRECHECK) != 0;
         uint32_t A = 0, healthy = 0;
-        // every lane loads its cell, the four neighbours and the reachability byte up front (clamped addresses, the
-        // words masked where the grid ends): one memory latency per pass, and nothing in a pass depends on the last one
+        // every lane takes its cell, the four neighbours and the reachability byte up front (clamped addresses, the
+        // words masked where the grid ends): nothing in a pass depends on the last one
 #pragma unroll 2
         for (uint32_t q0 = 0; q0 < cells; q0 += NT) {
             const uint32_t q = q0 + t;
@@ -900,13 +936,17 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
             const uint32_t qc = in ? q : cells - 1u;
             const uint32_t y = qc / W, x = qc - y * W;
             const bool top = y == 0, bottom = y == H - 1, left = x == 0, right = x == W - 1;
-            uint32_t c = se[qc];
-            const uint32_t vS = se[top ? qc : qc - W], vN = se[bottom ? qc : qc + W];
-            const uint32_t vE = se[left ? qc : qc - 1u], vW = se[right ? qc : qc + 1u];
-            const uint32_t rb = precheck ? (uint32_t)reach_e[qc] : 0u;
+            uint32_t c = src(qc);
+            const uint32_t vS = src(top ? qc : qc - W), vN = src(bottom ? qc : qc + W);
+            const uint32_t vE = src(left ? qc : qc - 1u), vW = src(right ? qc : qc + 1u);
+            uint32_t rb = 0;
+            if (precheck) {
+                if constexpr (STAGE) rb = board[qc] & 4u;
+                else rb = reach_e[qc];
+            }
             uint32_t ig = 0;
             if (upd && in) c = cell_tick<WIND>(c, bottom ? 0u : vN, top ? 0u : vS, left ? 0u : vE, right ? 0u : vW, ign, wc, threshold,
-                                         WIND ? a.wind_cnt + (size_t)e * cells + qc : nullptr, ig);
+                                               WIND ? a.wind_cnt + (size_t)e * cells + qc : nullptr, ig);
             if (in) de[q] = c;
             const uint32_t ty = c & 0xffu;
             const bool fire = in && (ty & 3u) == 1u;
@@ -924,7 +964,7 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
             healthy = red[slot][1];
             __syncthreads();
         }
-        if (t == 0) big_post_env(a, e, m, A, healthy, valid);
+        if (t == 0) big_post_env(a, e, m, A, healthy, valid, ev);
     }
 }
 
@@ -1031,21 +1071,30 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL(wf_big_pre, dim3(eb), dim3(256), 0, s, a, mode);
     if (per_env) {
-        // agent logic, then everything else of the step in one launch: a wave (grids up to 1 024 cells) or a workgroup
-        // per environment
+        // agent logic, then everything else of the step in one launch: a wave (grids up to 1 024 cells) or a workgroup per
+        // environment; grid + reachability bytes staged in LDS where that leaves eight workgroups per CU (20 KiB each:
+        // a 48x48 grid per wave with 46 KiB per workgroup ran at 3 waves per SIMD, 257 us against 110)
         const size_t cells = (size_t)a.H * a.W;
+        const bool cont = (a.hot_flags & WF_HOT_CONTAINMENT) != 0, wind = (a.hot_flags & WF_HOT_WIND) != 0;
+        size_t aux = cont ? cells : 0;                                           // byte board
+        if ((a.hot_flags & WF_HOT_RIVERS) && aux < (size_t)a.H * 2) aux = (size_t)a.H * 2;   // river row table
+        const size_t staged = (cells * 4 + aux + 15) & ~(size_t)15, plain = (aux + 15) & ~(size_t)15;
         const bool wave = cells <= 1024;
         const unsigned epb = wave ? 4u : 1u;
-        size_t slot = (a.hot_flags & WF_HOT_CONTAINMENT) ? cells : 0;
-        if ((a.hot_flags & WF_HOT_RIVERS) && slot < (size_t)a.H * 2) slot = (size_t)a.H * 2;
-        slot = (slot + 15) & ~(size_t)15;
+        const bool stage = staged * epb <= 20480;
+        const size_t slot = stage ? staged : plain;
         unsigned blocks = (unsigned)((a.batch + epb - 1) / epb);
         if (blocks > 8192) blocks = 8192;
-        const bool wind = (a.hot_flags & WF_HOT_WIND) != 0;
-        if (wave && wind) hipLaunchKernelGGL((wf_step_env<64, true>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
-        if (wave && !wind) hipLaunchKernelGGL((wf_step_env<64, false>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
-        if (!wave && wind) hipLaunchKernelGGL((wf_step_env<256, true>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
-        if (!wave && !wind) hipLaunchKernelGGL((wf_step_env<256, false>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot);
+#define WF_ENV_LAUNCH(NT, WIND, STAGE) \
+        hipLaunchKernelGGL((wf_step_env<NT, WIND, STAGE>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot)
+        if (wave) {
+            if (wind) { if (stage) WF_ENV_LAUNCH(64, true, true); else WF_ENV_LAUNCH(64, true, false); }
+            else { if (stage) WF_ENV_LAUNCH(64, false, true); else WF_ENV_LAUNCH(64, false, false); }
+        } else {
+            if (wind) { if (stage) WF_ENV_LAUNCH(256, true, true); else WF_ENV_LAUNCH(256, true, false); }
+            else { if (stage) WF_ENV_LAUNCH(256, false, true); else WF_ENV_LAUNCH(256, false, false); }
+        }
+#undef WF_ENV_LAUNCH
         return hipGetLastError();
     }
     if (a.hot_flags & WF_HOT_AUTO_RESET) {
