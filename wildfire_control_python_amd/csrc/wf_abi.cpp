@@ -355,7 +355,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         if ((e = hipMalloc((void **)&c->planes, cells * 4)) != hipSuccess) break;
         if (fam != WF_FAM_WAVE) {
             if (fam == WF_FAM_TILED) {   // in place + 64 B of halo masks per workgroup
-                if ((e = hipMalloc((void **)&c->d_halo, (size_t)batch * wf_tiled_groups(H) * 8 * sizeof(u64))) != hipSuccess) break;
+                if ((e = hipMalloc((void **)&c->d_halo, (size_t)batch * wf_tiled_groups(H, W) * 8 * sizeof(u64))) != hipSuccess) break;
             } else {
                 if ((e = hipMalloc((void **)&c->planes_alt, cells * 4)) != hipSuccess) break;
             }
@@ -635,7 +635,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             const bool want_obs = d_obs && st == n_steps - 1;
             const bool fused_obs = want_obs && c->fam == WF_FAM_TILED && wf_tiled_fused_obs(c->H, c->W);
             a.obs = fused_obs ? d_obs + (size_t)lo * cells * 3 : nullptr;
-            u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H) * 8 : nullptr;
+            u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H, c->W) * 8 : nullptr;
             hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
             HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 4, halo, c->p.seed, si,
                                           c->fam == WF_FAM_CELLS && wf_cells_per_env_kernel(c->batch, c->H, c->W, c->knobs)));

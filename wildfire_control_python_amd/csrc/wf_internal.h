@@ -117,7 +117,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
 #define WF_CELLS_FLOOD_MAX 60000   // generic family: cells of a grid whose reachability byte board fits the flood kernel's LDS
 // generic family: wf_big_pre -> wf_step_env instead of the five-launch sequence (decided for the context's whole batch)
 bool wf_cells_per_env_kernel(int batch, int H, int W, const WfKnobs &k);
-int wf_tiled_groups(int H);      // workgroups of wf_step_tiled per environment
+int wf_tiled_groups(int H, int W);   // workgroups of wf_step_tiled per environment
 bool wf_tiled_fused_obs(int H, int W);   // wf_step_tiled writes World.get_state() itself (a.obs != nullptr) for this shape
 // sel == nullptr: all envs; sel_value >= 0: envs with sel[e] == sel_value; sel_value < 0: envs with sel[e] != 0
 hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s);

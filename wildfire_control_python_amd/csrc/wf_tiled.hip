@@ -290,9 +290,8 @@ __device__ __forceinline__ void stage_obs_row(const ObsTile &ot, uint32_t r, uin
 // rows [row0, row0 + nrows) of the tile -> obs_e (this environment's (W, H, 3) block); nrows % 4 == 0
 __device__ __forceinline__ void flush_obs_tile(const ObsTile &ot, uint32_t nrows, uint32_t W, uint32_t H, int8_t *obs_e)
 {
-    const uint32_t x = threadIdx.x;
-    if (x >= W) return;
     struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+    for (uint32_t x = threadIdx.x; x < W; x += blockDim.x)
     for (uint32_t g = 0; g < nrows; g += 4u) {
         uint32_t v[4];
 #pragma unroll
@@ -305,11 +304,31 @@ __device__ __forceinline__ void flush_obs_tile(const ObsTile &ot, uint32_t nrows
     }
 }
 
-template <bool STEP, bool REACH, bool OBS>
-__device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, uint32_t ign, bool active, const uint4 &cur,
+// Packing (P > 1): a grid narrower than 128 cells leaves most of a wave's lanes without a quad, so the wave takes
+// P = 2 (W <= 128) or 4 (W <= 64) of its 16-row strips side by side: lane = (segment, quad), segment s sweeping rows
+// r0 + 16 s .. + 15 while segment 0 sweeps r0 .. r0 + 15.  Every mask then holds P rows' bits, 64/P lanes apart: the
+// vertical neighbours are still "the same bit of the adjacent step's masks" inside a segment; between segments the
+// last row of segment s-1 / the first row of segment s+1 come in by a shift of 64/P bits (tiled_sweep's Sabove / Sbelow);
+// the one-lane shifts of the horizontal neighbours must not cross a segment border.
+template <int P>
+struct Pack {
+    static constexpr uint32_t LWP = 64u / (uint32_t)P;                   // lanes per segment
+    static constexpr u64 SEG0 = P == 1 ? ~0ull : ((1ull << (LWP % 64u)) - 1ull);
+    static constexpr u64 X0 = P == 1 ? 1ull : P == 2 ? 0x0000000100000001ull : 0x0001000100010001ull;   // first lane of every segment
+    static constexpr u64 XE = X0 << (LWP - 1u);                          // last lane of every segment
+    uint32_t row_off;        // this lane's segment * 16: its row at sweep position r is r + row_off
+    uint32_t ql;             // this lane's quad within the row
+    bool col_ok;             // the quad exists (ql < W / 4)
+    u64 XL;                  // lane of the quad holding x == W-1, in every segment
+};
+
+template <bool STEP, bool REACH, bool OBS, int P>
+__device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, uint32_t ign, const Pack<P> &pk, const uint4 &cur,
                                           const u64 (&Sp)[4], const u64 (&Sc)[4], const u64 (&Sn)[4], const u64 *reach_e,
                                           const TiledDst &dst, const ObsTile &ot, TiledAcc &A)
 {
+    const uint32_t row = r + pk.row_off;
+    const bool active = pk.col_ok && row < H;
     uint32_t c[4] = { cur.x, cur.y, cur.z, cur.w };
     u64 FIRE[4], GR[4];
     if constexpr (STEP) {
@@ -323,8 +342,8 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
             const u64 G = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);   // idle lanes hold inert (dirt) cells
             // get_neighbours radius 1 (:311-326): above/below = same bit of the adjacent rows; every
             // neighbour set is counted by one add-with-carry-in
-            const u64 LF = j > 0 ? Sc[(j + 3) & 3] : (Sc[3] << 1);
-            const u64 RT = j < 3 ? Sc[(j + 1) & 3] : (Sc[0] >> 1);
+            const u64 LF = j > 0 ? Sc[(j + 3) & 3] : ((Sc[3] << 1) & (P == 1 ? ~0ull : ~Pack<P>::X0));
+            const u64 RT = j < 3 ? Sc[(j + 1) & 3] : ((Sc[0] >> 1) & (P == 1 ? ~0ull : ~Pack<P>::XE));
             const uint32_t cnt = addc0(addc0(addc0(lanebit(Sp[j]) ? 1u : 0u, Sn[j]), LF), RT);
             const uint32_t room = ign - ((c[j] >> 16) & 0xffu);
             const u64 IGN = G & __ballot(cnt >= room);                     // apply_heat_from_to :278-294
@@ -337,7 +356,11 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
             GR[j] = G & ~IGN;
         }
         // set_fire_to :245-246: first / last row of the grid are border rows
-        if ((r == 0 || r == H - 1) && anyign) A.bhit = 1;
+        if constexpr (P == 1) {
+            if ((r == 0 || r == H - 1) && anyign) A.bhit = 1;
+        } else {
+            if (anyign & __ballot(row == 0 || row == H - 1)) A.bhit = 1;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -348,13 +371,20 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
     if constexpr (REACH) {   // does a burning cell sit on a border-connected cell?
         typedef u64 u64x4 __attribute__((ext_vector_type(4)));
         typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
-        const u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
+        u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
+        if constexpr (P > 1) {      // the board rows of the other segments, moved to their lanes (rows past the grid: no fire bit meets them)
+#pragma unroll
+            for (int sgm = 1; sgm < P; ++sgm) {
+                const u64x4 rs = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)min(r + (uint32_t)sgm * (uint32_t)TR, H - 1u) * 4);
+                rb |= rs << (u64)(sgm * (int)Pack<P>::LWP);
+            }
+        }
         A.reach_hit |= ((FIRE[0] & rb.x) | (FIRE[1] & rb.y) | (FIRE[2] & rb.z) | (FIRE[3] & rb.w)) ? 1u : 0u;
     }
     A.anyfire |= (FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) ? 1u : 0u;
     A.healthy += (uint32_t)(__popcll(GR[0]) + __popcll(GR[1]) + __popcll(GR[2]) + __popcll(GR[3]));
     if constexpr (OBS) {
-        if (active) stage_obs_row(ot, r, __lane_id(), c);
+        if (active) stage_obs_row(ot, row, pk.ql, c);
     }
     if constexpr (STEP) {
         if (active && ((c[0] ^ cur.x) | (c[1] ^ cur.y) | (c[2] ^ cur.z) | (c[3] ^ cur.w)))
@@ -362,8 +392,8 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
     }
 }
 
-template <bool STEP, bool REACH, bool OBS>
-__device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, bool active,
+template <bool STEP, bool REACH, bool OBS, int P>
+__device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, const Pack<P> &pk,
                                             const uint4 *src, const TiledDst &dst, const ObsTile &ot, const uint4 &first, const u64 (&Sf)[4],
                                             const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, TiledAcc &A)
 {
@@ -372,7 +402,7 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
     u64 M[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { M[0][j] = Sf[j]; M[2][j] = Sabove[j]; M[1][j] = 0; }
-    if (r0 + 1 < r1 && active) C[1] = src[(r0 + 1u) * LW];
+    if (r0 + 1 < r1 && pk.col_ok && r0 + 1u + pk.row_off < H) C[1] = src[(r0 + 1u) * LW];
     for (uint32_t r = r0; r < r1; r += 3u) {
         static_for<3>([&](auto K) {
             constexpr int k = decltype(K)::value, kn = (k + 1) % 3, kp = (k + 2) % 3;
@@ -380,14 +410,14 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
             if (rr < r1) {
                 // the registers of row rr-1 are free: request row rr+2 into them
                 C[kp] = inert;
-                if (rr + 2 < r1 && active) C[kp] = src[(rr + 2u) * LW];
+                if (rr + 2 < r1 && pk.col_ok && rr + 2u + pk.row_off < H) C[kp] = src[(rr + 2u) * LW];
                 u64 Sn[4];
                 if (rr + 1 < r1) still_masks(C[kn], Sn);
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Sn[j] = Sbelow[j];
                 }
-                tiled_row<STEP, REACH, OBS>(rr, H, LW, ign, active, C[k], M[kp], M[k], Sn, reach_e, dst, ot, A);
+                tiled_row<STEP, REACH, OBS, P>(rr, H, LW, ign, pk, C[k], M[kp], M[k], Sn, reach_e, dst, ot, A);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) M[kn][j] = Sn[j];
             }
@@ -395,83 +425,92 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
     }
 }
 
-template <bool OBS>
+// Workgroup = nw waves (blockDim.x / 64: 4, fewer for grids that need fewer), wave = P strips of 16 rows side by side.
+template <bool OBS, int P>
 __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer)
 {
-    __shared__ u64 halo[4][2][4];                    // [strip][first,last row][component]
-    extern __shared__ __attribute__((aligned(16))) uint8_t obs_lds[];     // OBS: [64][W*3] (+4) staging tile
+    __shared__ u64 halo[4][2][4];                    // [wave][first,last row of each of its segments][component]
+    __shared__ uint16_t river_tab[4][64];            // auto-reset with rivers: water column of each of a wave's rows
+    extern __shared__ __attribute__((aligned(16))) uint8_t obs_lds[];     // OBS: [rows of the workgroup][W*3] (+4) staging tile
+    constexpr uint32_t LWP = Pack<P>::LWP, WR = (uint32_t)P * (uint32_t)TR;          // lanes per segment, rows per wave
     const uint32_t lane = __lane_id();
-    const uint32_t wv = rfl(threadIdx.x >> 6);
+    const uint32_t wv = rfl(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
-    const uint32_t gx = (H + 4u * TR - 1u) / (4u * TR);          // workgroups per environment
+    const uint32_t gx = (H + nw * WR - 1u) / (nw * WR);          // workgroups per environment
     const uint32_t e = blockIdx.x / gx;
-    const uint32_t r0 = ((blockIdx.x % gx) * 4u + wv) * TR;
-    const uint32_t r1 = min(r0 + TR, H);
+    const uint32_t r0 = ((blockIdx.x % gx) * nw + wv) * WR;      // segment 0's first row; segment s: r0 + 16 s
+    const uint32_t r1 = min(r0 + TR, H);                         // end of the sweep (segment 0's rows)
     const bool has_rows = r0 < H;
-    const bool active = lane < LW;
+    Pack<P> pk;
+    pk.row_off = (P == 1 ? 0u : lane / LWP) * (uint32_t)TR;
+    pk.ql = P == 1 ? lane : lane % LWP;
+    pk.col_ok = pk.ql < LW;
+    pk.XL = Pack<P>::X0 << (LW - 1u);
+    const uint32_t lane_cell0 = pk.row_off * LW + pk.ql;         // this lane's quad index at sweep position 0 (+ r * LW)
     const uint32_t ign = (uint32_t)a.ignite_count;
     const uint32_t md = mode[e];
-    const uint32_t wg_row0 = (blockIdx.x % gx) * 4u * TR;
+    const uint32_t wg_row0 = (blockIdx.x % gx) * nw * WR;
     const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
     int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
     if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
         const bool fresh = (md & MODE_MASK) == MODE_RESET;  // auto-reset: World.reset() of this environment's cells, here
         if (fresh || OBS) {                                // (a frozen one still owes its observation)
-            uint4 *rows = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane;
+            uint4 *rows = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane_cell0;
             const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);          // fresh: written by the prologue
             const EnvKey key(a.cold->p.seed, a.cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
             const ResetLaw L = reset_law(a, ev);
             const bool rivers = fresh && a.cold->p.make_rivers != 0;
             bool border_fire = false;
-            // reset_map's river: the wave walks it once and keeps the columns of its own 16 rows (0xffff: none) in its
-            // slice of the - here unused - strip-halo LDS words
-            uint16_t *river_col = reinterpret_cast<uint16_t *>(&halo[0][0][0]) + wv * TR;
+            // reset_map's river: the wave walks it once and keeps the columns of its own rows (0xffff: none)
+            uint16_t *river_col = river_tab[wv];
             if (rivers) {
-                if (lane < (uint32_t)TR) river_col[lane] = 0xffffu;
+                river_col[lane] = 0xffffu;
                 river_cells(key, (int)W, (int)H, [&](int x, int y) {
-                    if ((uint32_t)y - r0 < (uint32_t)TR && lane == 0) river_col[(uint32_t)y - r0] = (uint16_t)x;
+                    if ((uint32_t)y - r0 < WR && lane == 0) river_col[(uint32_t)y - r0] = (uint16_t)x;
                 });
             }
             for (uint32_t r = r0; r < r1; ++r) {
-                uint32_t cq[4];
+                const uint32_t row = r + pk.row_off;
+                const bool active = pk.col_ok && row < H;
+                uint32_t cq[4] = { 0, 0, 0, 0 };
                 if (fresh) {
-                    const uint32_t rcol = rivers ? (uint32_t)river_col[r - r0] : 0xffffu;
+                    if (active) {
+                        const uint32_t rcol = rivers ? (uint32_t)river_col[row - r0] : 0xffffu;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) cq[j] = reset_cell(L, key, r * W + 4u * lane + (uint32_t)j, 4u * lane + (uint32_t)j, r, rcol, border_fire);
-                    if (active) rows[r * LW] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+                        for (int j = 0; j < 4; ++j) cq[j] = reset_cell(L, key, row * W + 4u * pk.ql + (uint32_t)j, 4u * pk.ql + (uint32_t)j, row, rcol, border_fire);
+                        rows[r * LW] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+                    }
                 } else if (active) {
                     const uint4 q = rows[r * LW];
                     cq[0] = q.x; cq[1] = q.y; cq[2] = q.z; cq[3] = q.w;
                 }
                 if constexpr (OBS) {
-                    if (active) stage_obs_row(ot, r, lane, cq);
+                    if (active) stage_obs_row(ot, row, pk.ql, cq);
                 }
             }
-            if (__ballot(border_fire && active) && lane == 0)
+            if (__ballot(border_fire) && lane == 0)
                 atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
         }
         if constexpr (OBS) {
             __syncthreads();
-            flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
+            flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
         }
         return;
     }
     const bool step = (a.update_mask & 1ull) != 0;
     const bool reach_test = (md & MODE_PRECHECK) != 0;
-    const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4] in this kernel's mask layout
+    const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4], bit = quad of the row
     // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
-    const TiledDst dst = { __builtin_amdgcn_make_buffer_rsrc(a.planes + (size_t)e * H * W, 0, (int)(H * W * 4u), 0x00020000), lane * 16u };
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane_cell0;
+    const TiledDst dst = { __builtin_amdgcn_make_buffer_rsrc(a.planes + (size_t)e * H * W, 0, (int)(H * W * 4u), 0x00020000), lane_cell0 * 16u };
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
 
-    // ---- prologue: masks of the strip's first and last row -> LDS
+    // ---- prologue: masks of every segment's first and last row (original state) -> LDS
     uint4 first = inert, last = inert;
     u64 Sf[4] = { 0, 0, 0, 0 }, Sl[4] = { 0, 0, 0, 0 };
     if (has_rows) {
-        if (active) {
-            first = src[r0 * LW];
-            last = src[(r1 - 1u) * LW];
-        }
+        if (pk.col_ok && r0 + pk.row_off < H) first = src[r0 * LW];
+        if (pk.col_ok && r1 - 1u + pk.row_off < H) last = src[(r1 - 1u) * LW];
         still_masks(first, Sf);
         still_masks(last, Sl);
     }
@@ -483,33 +522,41 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     TiledAcc A = { 0, 0, 0, 0, 0, 0 };
     if (has_rows) {                                        // (a wave without rows of its own still flushes and arrives below)
 
-    // masks of the row above the strip / below the strip (original state): neighbour strip through LDS,
-    // neighbour workgroup from the saved outer halos
+    // masks of the row above / below every segment (original state).  Segment 0's row above: the last segment of the
+    // wave before (LDS) or of the workgroup before (the saved outer halos); the last segment's row below likewise; the
+    // segments in between see each other's last / first rows through a shift of one segment
     u64 Sp[4] = { 0, 0, 0, 0 }, Sb[4] = { 0, 0, 0, 0 };
     if (r0 > 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u64 v = wv > 0 ? halo[wv - 1][1][j] : outer[(size_t)blockIdx.x * 8 + j];
-            Sp[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+            const u64 v = wv > 0 ? (halo[wv - 1][1][j] >> (LWP * (uint32_t)(P - 1))) : outer[(size_t)blockIdx.x * 8 + j];
+            Sp[j] = (((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0;
         }
     }
-    if (r1 < H) {
+    if (r0 + WR < H) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u64 v = wv < 3 ? halo[wv + 1][0][j] : outer[(size_t)blockIdx.x * 8 + 4 + j];
-            Sb[j] = ((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+            const u64 v = wv + 1u < nw ? halo[wv + 1][0][j] : outer[(size_t)blockIdx.x * 8 + 4 + j];
+            Sb[j] = ((((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0) << (LWP * (uint32_t)(P - 1));
+        }
+    }
+    if constexpr (P > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Sp[j] |= Sl[j] << LWP;
+            Sb[j] |= Sf[j] >> LWP;
         }
     }
 
     // ---- sweep
     if (step) {
-        if (reach_test) tiled_sweep<true, true, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
-        else tiled_sweep<true, false, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        if (reach_test) tiled_sweep<true, true, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        else tiled_sweep<true, false, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
     } else {
-        if (reach_test) tiled_sweep<false, true, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
-        else tiled_sweep<false, false, OBS>(r0, r1, H, LW, ign, active, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        if (reach_test) tiled_sweep<false, true, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        else tiled_sweep<false, false, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
     }
-    A.bhit |= ((A.ign_x0 & 1ull) | (A.ign_xl & (1ull << (LW - 1)))) ? 1u : 0u;      // x == 0 / x == W-1 columns
+    A.bhit |= ((A.ign_x0 & Pack<P>::X0) | (A.ign_xl & pk.XL)) ? 1u : 0u;      // x == 0 / x == W-1 columns
     if (lane == 0) {
         // device-scope atomics are performed at the memory side (the per-XCD L2s are not coherent with each other);
         // the RETURNING forms, consumed, make the wave wait until they have been
@@ -521,7 +568,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     }
     }   // has_rows
     __syncthreads();
-    if constexpr (OBS) flush_obs_tile(ot, min(4u * TR, H - wg_row0), W, H, obs_e);
+    if constexpr (OBS) flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
     // ---- World.RUNNING / reward / done of the environment: by whichever of its gx workgroups arrives last (every wave
     // of this workgroup has its reduction atomics behind it: the barrier above).  No data but the atomically updated
     // words passes between the workgroups, so no cache write-back fence is needed.
@@ -535,6 +582,54 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     }
 }
 
+// bit i of the low 16 bits -> bit 4i; and back
+__device__ __forceinline__ u64 spread4(u64 v)
+{
+    v &= 0xFFFFull;
+    v = (v | (v << 24)) & 0x000000FF000000FFull;
+    v = (v | (v << 12)) & 0x000F000F000F000Full;
+    v = (v | (v << 6)) & 0x0303030303030303ull;
+    v = (v | (v << 3)) & 0x1111111111111111ull;
+    return v;
+}
+
+__device__ __forceinline__ u64 squeeze4(u64 v)
+{
+    v &= 0x1111111111111111ull;
+    v = (v | (v >> 3)) & 0x0303030303030303ull;
+    v = (v | (v >> 6)) & 0x000F000F000F000Full;
+    v = (v | (v >> 12)) & 0x000000FF000000FFull;
+    v = (v | (v >> 24)) & 0xFFFFull;
+    return v;
+}
+
+// Flood the seeds s (a subset of p) along the runs of ones of the 256-bit row p, towards both ends: adding a seed to
+// its run carries through the rest of the run, so (p ^ (p + s)) & p is everything from a seed up to the run's end;
+// the same on the bit-reversed row fills downwards.
+__device__ __forceinline__ void fill_runs(const u64 (&p)[4], u64 (&s)[4])
+{
+    u64 up[4], dn[4];
+    unsigned char carry = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const u64 t = p[w] + s[w], t2 = t + carry;
+        const unsigned char c2 = (t < p[w]) | (t2 < t);
+        up[w] = ((p[w] ^ t2) & p[w]) | s[w];
+        carry = c2;
+    }
+    carry = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                       // reversed row: word 3 - w, bits reversed
+        const u64 pr = __brevll(p[3 - w]), sr = __brevll(s[3 - w]);
+        const u64 t = pr + sr, t2 = t + carry;
+        const unsigned char c2 = (t < pr) | (t2 < t);
+        dn[3 - w] = __brevll(((pr ^ t2) & pr) | sr);
+        carry = c2;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s[w] = up[w] | dn[w];
+}
+
 // ---------------------------------------------------------------------------- prologue of a tiled step
 // One workgroup per environment does everything that has to precede the in-place tick, in ONE launch (it used to be
 // three: each kernel boundary of a step costs ~4.5 us that nothing overlaps):
@@ -544,7 +639,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
 //      4-connected to a passable border cell through passable cells;
 //   3. the still-burning masks of the two rows just outside every workgroup of wf_step_tiled, taken from the state
 //      BEFORE the tick: halo[(e*gx + g)*8 + 0..3] = row above workgroup g, +4..7 = row below (one wave per row).
-__global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t *mode, u64 *halo)
+__global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t *mode, u64 *halo, uint32_t rows_per_wg)
 {
     extern __shared__ u64 lds[];                     // flood: [H*4] pass, [H*4] reach
     __shared__ uint32_t s_mode, changed;
@@ -565,46 +660,71 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
     if (md & MODE_FLOOD) {                                           // (only set with the containment test on)
         u64 *pass = lds, *reach = lds + words;
-        // passable masks, one row per wave iteration
+        // passable masks, one row per wave iteration; kept LINEAR for the flood: bit x % 64 of word [r][x / 64]
+        // (the ballots give the interleaved layout of the tick - bit l of component j = cell x = 4l + j)
         for (uint32_t r = wv; r < H; r += 4u) {
             uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
             if (lane < LW) c = src[r * LW];
-            const u64 p0 = __ballot((c.x & 0xffu) < WF_DIRT), p1 = __ballot((c.y & 0xffu) < WF_DIRT);
-            const u64 p2 = __ballot((c.z & 0xffu) < WF_DIRT), p3 = __ballot((c.w & 0xffu) < WF_DIRT);
-            if (lane == 0) {
+            const u64 P[4] = { __ballot((c.x & 0xffu) < WF_DIRT), __ballot((c.y & 0xffu) < WF_DIRT),
+                               __ballot((c.z & 0xffu) < WF_DIRT), __ballot((c.w & 0xffu) < WF_DIRT) };
+            if (lane < 4u) {
+                const uint32_t w = lane;                             // linear word w holds the quads 16w .. 16w+15
+                const u64 lin = spread4(P[0] >> (16u * w)) | (spread4(P[1] >> (16u * w)) << 1) |
+                                (spread4(P[2] >> (16u * w)) << 2) | (spread4(P[3] >> (16u * w)) << 3);
+                pass[r * 4 + w] = lin;
+                // seeds: passable border cells (first / last row; x == 0; x == W-1)
                 const bool edge = r == 0 || r == H - 1;
-                const u64 P[4] = { p0, p1, p2, p3 };
-                for (int j = 0; j < 4; ++j) {
-                    pass[r * 4 + j] = P[j];
-                    // seeds: passable border cells (first/last row; x == 0 -> word 0 bit 0; x == W-1 -> word 3 bit LW-1)
-                    const u64 bm = edge ? ~0ull : (j == 0 ? 1ull : (j == 3 ? (1ull << (LW - 1)) : 0ull));
-                    reach[r * 4 + j] = P[j] & bm;
-                }
+                u64 bm = edge ? ~0ull : 0ull;
+                if (w == 0) bm |= 1ull;
+                if (w == (W - 1u) >> 6) bm |= 1ull << ((W - 1u) & 63u);
+                reach[r * 4 + w] = lin & bm;
             }
         }
         __syncthreads();
-        // A relaxation sweep advances the front by at least one cell along every shortest path, and a shortest path
-        // through passable cells has fewer than H*W cells (a serpentine between dirt walls comes close): H*W sweeps
-        // always suffice, like the wave and cell floods; a mere 4*(H+W) would not.
+        // Relaxation, one thread per row: take what the rows above and below have reached, then fill along the row's
+        // passable runs in both directions at once (a carry runs through a run of ones: fill_runs).  A sweep so advances
+        // a whole horizontal run and one row per step; the open field outside a dug ring converges in two or three
+        // sweeps where the cell-by-cell relaxation needed as many as the grid is wide.  H*W sweeps always suffice.
         bool converged = false;
         for (uint32_t it = 0; it < H * W; ++it) {
             if (threadIdx.x == 0) changed = 0;
             __syncthreads();
             bool ch = false;
-            for (uint32_t k = threadIdx.x; k < words; k += 256u) {
-                const uint32_t r = k >> 2, j = k & 3u;
-                const u64 cur = reach[k];
-                u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);
-                nb |= j > 0 ? reach[k - 1] : (reach[k + 3] << 1);
-                nb |= j < 3 ? reach[k + 1] : (reach[k - 3] >> 1);
-                const u64 nw = cur | (nb & pass[k]);
-                if (nw != cur) { reach[k] = nw; ch = true; }
+            for (uint32_t r = threadIdx.x; r < H; r += 256u) {
+                u64 p[4], s4[4];
+                bool grew = false;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    p[w] = pass[r * 4 + w];
+                    const u64 cur = reach[r * 4 + w];
+                    s4[w] = (cur | (r > 0 ? reach[r * 4 - 4 + w] : 0ull) | (r + 1 < H ? reach[r * 4 + 4 + w] : 0ull)) & p[w];
+                }
+                fill_runs(p, s4);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (s4[w] != reach[r * 4 + w]) { reach[r * 4 + w] = s4[w]; grew = true; }
+                }
+                ch |= grew;
             }
             if (ch) changed = 1;
             __syncthreads();
             if (!changed) { converged = true; break; }
             __syncthreads();
         }
+        // back to the tick's interleaved layout, in place: component j of row r = every fourth bit from bit j
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < H; r += 256u) {
+            u64 lin[4], il[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int w = 0; w < 4; ++w) lin[w] = reach[r * 4 + w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) il[j] |= squeeze4(lin[w] >> j) << (16 * w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reach[r * 4 + j] = il[j];
+        }
+        __syncthreads();
         u64 *out = a.reach + (size_t)e * words;
         if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
             // Burning dirt (WF_DIRT_BURNING) is impassable, yet the reference's search starts FROM it: it reaches the
@@ -631,10 +751,10 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
     if (threadIdx.x == 0 && have_record) *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
     // ---- outer halos
     if ((md & MODE_MASK) != MODE_STEP || !halo) return;
-    const uint32_t gx = (H + 4u * TR - 1u) / (4u * TR);
+    const uint32_t gx = (H + rows_per_wg - 1u) / rows_per_wg;
     for (uint32_t task = wv; task < gx * 2u; task += 4u) {
         const uint32_t side = task & 1u, g = task >> 1;
-        const uint32_t first = g * 4u * TR, endr = min(first + 4u * TR, H);
+        const uint32_t first = g * rows_per_wg, endr = min(first + rows_per_wg, H);
         if (side == 0 ? first == 0 : endr >= H) continue;                  // grid edge: no such row
         const uint32_t r = side == 0 ? first - 1u : endr;
         uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
@@ -929,7 +1049,6 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
         uint32_t A = 0, healthy = 0;
         // every lane takes its cell, the four neighbours and the reachability byte up front (clamped addresses, the
         // words masked where the grid ends): nothing in a pass depends on the last one
-#pragma unroll 2
         for (uint32_t q0 = 0; q0 < cells; q0 += NT) {
             const uint32_t q = q0 + t;
             const bool in = q < cells;
@@ -1047,7 +1166,21 @@ bool wf_cells_per_env_kernel(int batch, int H, int W, const WfKnobs &k)
     return !k.cells_legacy && (cells <= 1024 || batch >= 512);
 }
 
-int wf_tiled_groups(int H) { return (H + 4 * TR - 1) / (4 * TR); }
+// Shape of a wf_step_tiled launch: strips packed side by side per wave, waves per workgroup, workgroups per environment
+struct TiledShape { int P, nw, rows_per_wg, gx; };
+static TiledShape tiled_shape(int H, int W)
+{
+    TiledShape t;
+    const int LW = W / 4;
+    t.P = LW <= 16 ? 4 : LW <= 32 ? 2 : 1;
+    const int rows_per_wave = t.P * TR;
+    t.nw = (H + rows_per_wave - 1) / rows_per_wave;
+    if (t.nw > 4) t.nw = 4;
+    t.rows_per_wg = t.nw * rows_per_wave;
+    t.gx = (H + t.rows_per_wg - 1) / t.rows_per_wg;
+    return t;
+}
+int wf_tiled_groups(int H, int W) { return tiled_shape(H, W).gx; }
 
 // wf_step_tiled can write the observation itself when the (x, y-run) blocks of obs are 4-byte aligned
 bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
@@ -1058,14 +1191,18 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         // prologue (agent logic, reachability flood, outer halos) -> the in-place tick, which also writes the fresh
         // grids of environments that are being auto-reset and whose last workgroup per environment does
         // World.RUNNING / reward / done
-        const unsigned gx = (unsigned)((a.H + 4 * TR - 1) / (4 * TR));
+        const TiledShape ts = tiled_shape(a.H, a.W);
+        const unsigned gx = (unsigned)ts.gx;
         const size_t flood_lds = (a.hot_flags & WF_HOT_CONTAINMENT) ? (size_t)a.H * 4 * 8 * 2 : 0;
-        hipLaunchKernelGGL(wf_tiled_prologue, dim3((unsigned)a.batch), dim3(256), flood_lds, s, a, mode, gx > 1 ? halo : (u64 *)nullptr);
+        hipLaunchKernelGGL(wf_tiled_prologue, dim3((unsigned)a.batch), dim3(256), flood_lds, s, a, mode, gx > 1 ? halo : (u64 *)nullptr,
+                           (uint32_t)ts.rows_per_wg);
         (void)auto_seed;       // == cold->p.seed: finished environments are reset by the tick kernel itself
-        if (a.obs)      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
-            hipLaunchKernelGGL(wf_step_tiled<true>, dim3(gx * (unsigned)a.batch), dim3(256), (size_t)(4 * TR) * a.W * 3 + 16, s, a, mode, acc, (const u64 *)halo);
-        else
-            hipLaunchKernelGGL(wf_step_tiled<false>, dim3(gx * (unsigned)a.batch), dim3(256), 0, s, a, mode, acc, (const u64 *)halo);
+        const dim3 grid(gx * (unsigned)a.batch), block(64u * (unsigned)ts.nw);
+        const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * a.W * 3 + 16 : 0;      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
+#define WF_TILED_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P>), grid, block, obs_lds, s, a, mode, acc, (const u64 *)halo)
+        if (a.obs) { if (ts.P == 4) WF_TILED_LAUNCH(true, 4); else if (ts.P == 2) WF_TILED_LAUNCH(true, 2); else WF_TILED_LAUNCH(true, 1); }
+        else { if (ts.P == 4) WF_TILED_LAUNCH(false, 4); else if (ts.P == 2) WF_TILED_LAUNCH(false, 2); else WF_TILED_LAUNCH(false, 1); }
+#undef WF_TILED_LAUNCH
         return hipGetLastError();
     }
     const unsigned eb = (unsigned)((a.batch + 255) / 256);
