@@ -170,9 +170,9 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               # generic family: a wave per environment (up to 1 024 cells), a workgroup per environment (more cells, 512+
               # environments), the thread-per-cell sequence (few huge grids, or WF_CELLS_LEGACY=1: marked by a negative B)
               (50, 42, 520), (11, 11, -128), (30, 23, -48), (15, 15, 700),
-              # small grids the tiled family can serve go to the generic one (faster up to 48x48); WF_FAMILY=tiled keeps
-              # the tiled kernels covered there (marked by B + 10000)
-              (24, 24, 10096), (32, 20, 10064), (48, 48, 10024)]
+              # small grids the tiled family can serve go to the generic one (faster below 32x32); WF_FAMILY=tiled keeps
+              # the tiled kernels covered there (marked by B + 10000); packed strips: 4 per wave up to W = 64, 2 up to 128
+              (24, 24, 10096), (32, 20, 10064), (48, 48, 24), (64, 100, 12), (128, 128, 6), (36, 30, 40)]
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)
@@ -190,7 +190,7 @@ def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
                                auto_reset=auto)
     assert "tiled" in env.kernel_name or "cells" in env.kernel_name
-    assert ("tiled" in env.kernel_name) == (W % 4 == 0 and W <= 256 and (W * H > 2304 or forced_tiled))
+    assert ("tiled" in env.kernel_name) == (W % 4 == 0 and W <= 256 and (W * H > 1023 or forced_tiled))
     if "cells" in env.kernel_name:
         legacy = "WF_CELLS_LEGACY" in __import__("os").environ or (W * H > 1024 and B < 512)
         assert env.step_kernel == ("wf_step_cells" if legacy else "wf_step_env")

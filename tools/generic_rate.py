@@ -12,7 +12,7 @@ import wildfire_control_python_amd as pkg
 
 ONLY = len(sys.argv) > 1 and sys.argv[1] == "only"          # "only": the headline size with wind "random" only (profiling)
 SWEEP = [(B, S, [0.54, (0, 0)], fam) for S, B in ((16, 65536), (20, 32768), (24, 32768), (32, 16384), (48, 8192), (64, 4096), (100, 2048), (128, 1024))
-         for fam in (0, 2)]
+         for fam in (0, 2, 3)]
 CASES = SWEEP if len(sys.argv) > 1 and sys.argv[1] == "sweep" else [(65536, 14, "random", 0), (65536, 14, "random", 1), (65536, 14, [0.54, (0, 0)], 0),
          (65536, 15, [0.54, (0, 0)], 0), (65536, 15, [0.54, (0, 0)], 1), (65536, 13, [0.54, (0, 0)], 0),
          (8192, 50, [0.54, (0, 0)], 0), (8192, 50, [0.54, (0, 0)], 1), (8192, 52, [0.54, (0, 0)], 0),
@@ -25,6 +25,8 @@ for B, S, wind, legacy in CASES[:1 if ONLY else None]:
             os.environ["WF_CELLS_LEGACY"] = "1"
         if legacy == 2:
             os.environ["WF_FAMILY"] = "cells"
+        if legacy == 3:
+            os.environ["WF_FAMILY"] = "tiled"
         env = pkg.BatchedForestFire(B, size=S, seed=1234, auto_reset=True, fuel_range=(10, 40), metadata={"wind": wind},
                                     ignite_ppm=10000 if S >= 250 else 0, containment=(S * S <= 60000) and None)
         env.reset(seed=5)

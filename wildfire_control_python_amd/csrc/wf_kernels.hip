@@ -427,9 +427,9 @@ WfFamily wf_pick_family(int H, int W)
 #define X(w, h) if (W == w && H == h) return WF_FAM_WAVE;
     WF_WAVE_SHAPES(X)
 #undef X
-    // row-strip tiles use W/4 lanes of a wave and 16 rows per wave: small grids leave most of both idle, and the
-    // generic family's wave-per-environment kernel is faster up to 48x48 (20x20: 68 against 380 us per 13 M cells,
-    // 32x32: 123 against 220, 48x48: 117 against 134; 64x64: 181 against 86)
+    // the tiled family costs a 256-thread prologue workgroup per environment and sweeps at most 4 x 16 rows per wave:
+    // below 32x32 the generic family's wave-per-environment kernel is faster (us per 13 M cells: 20x20 68 against 204,
+    // 24x24 92 against 211; 32x32 123 against 111, 48x48 116 against 69, 64x64 182 against 54)
     if (W >= 4 && W <= 256 && W % 4 == 0 && H >= 1 && (long long)H * W > WF_TILED_MIN_CELLS) return WF_FAM_TILED;
     return WF_FAM_CELLS;
 }

@@ -930,10 +930,16 @@ __device__ __forceinline__ void env_sync()
 
 // STAGE: the environment's grid (and its reachability bytes) fit the slot's LDS: they are staged there by batched,
 // independent loads - one memory latency per environment instead of one per pass - and flood and tick read LDS.
-template <int NT, bool WIND, bool STAGE>
-__global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t *mode, uint32_t slot_bytes)
+// BM: the flood runs on linear row bitmaps (wf_tiled_prologue's run fill) - instantiated for the workgroup-per-environment
+// grids only: its 256-bit row arithmetic costs the wave-per-environment kernel half its occupancy.
+#ifndef WF_ENV_WAVES
+#define WF_ENV_WAVES 6          // waves per SIMD of the wave-per-environment instantiations (4 / 6 / 8: 101 / 91 / 93 us per 65 536 x 14x14 wind step)
+#endif
+template <int NT, bool WIND, bool STAGE, bool BM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? WF_ENV_WAVES : 4, 8))) void wf_step_env(const WfArgs a, const uint8_t *mode, uint32_t slot_bytes, uint32_t bm_off)
 {
     // per environment slot: [STAGE: the grid, one word per cell] [reachability byte board | river row table]
+    // [bm_off != 0: two linear row bitmaps of 256 bits per row for the flood (W <= 256)]
     extern __shared__ __attribute__((aligned(16))) uint8_t env_lds[];
     constexpr uint32_t EPB = 256 / NT;
     __shared__ uint32_t red[EPB][4];                 // flags, healthy, changed (flood), -
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H, cells = W * H;
     const uint32_t ign = (uint32_t)a.ignite_count;
     uint32_t *ls = reinterpret_cast<uint32_t *>(env_lds + (size_t)slot * slot_bytes);
-    uint8_t *board = env_lds + (size_t)slot * slot_bytes + (STAGE ? (size_t)cells * 4 : 0);
+    uint8_t *board = env_lds + (size_t)slot * slot_bytes + (STAGE ? (((size_t)cells * 4 + 15) & ~(size_t)15) : 0);
     const WfCold *cold = a.cold;
     for (uint32_t e = blockIdx.x * EPB + slot; e < (uint32_t)a.batch; e += gridDim.x * EPB) {
         // everything this environment needs from memory is requested up front - mode, record, and (STAGE) the whole
@@ -1002,7 +1008,59 @@ __global__ __launch_bounds__(256) void wf_step_env(const WfArgs a, const uint8_t
         const bool upd = (a.update_mask & 1ull) != 0, precheck = (m & MODE_PRECHECK) != 0, flood = (m & MODE_FLOOD) != 0;
         auto src = [&](uint32_t q) -> uint32_t { if constexpr (STAGE) return ls[q]; else return se[q]; };
         uint32_t valid = 0;
-        if (flood) {
+        if (BM && flood && bm_off) {
+            // border-reachability board through linear row bitmaps (as wf_tiled_prologue): passable cells and seeds per
+            // row, then one thread per row takes what the rows above and below reached and fills along the row's runs
+            u64 *pass = reinterpret_cast<u64 *>(env_lds + (size_t)slot * slot_bytes + bm_off), *reach = pass + H * 4u;
+            for (uint32_t k = t; k < H * 4u; k += NT) {
+                const uint32_t r = k >> 2, w = k & 3u, x0 = w * 64u;
+                u64 mk = 0;
+                if (x0 < W) {
+                    const uint32_t n = min(64u, W - x0);
+                    for (uint32_t i = 0; i < n; ++i) mk |= (u64)((src(r * W + x0 + i) & 0xffu) < (uint32_t)WF_DIRT ? 1u : 0u) << i;
+                }
+                pass[k] = mk;
+                u64 seeds = (r == 0 || r == H - 1) ? ~0ull : 0ull;
+                if (w == 0) seeds |= 1ull;
+                if (w == (W - 1u) >> 6) seeds |= 1ull << ((W - 1u) & 63u);
+                reach[k] = mk & seeds;
+            }
+            env_sync<NT>();
+            for (uint32_t it = 0; it < cells; ++it) {
+                if (t == 0) red[slot][2] = 0;
+                env_sync<NT>();
+                bool ch = false;
+                for (uint32_t r = t; r < H; r += NT) {
+                    u64 p4[4], s4[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        p4[w] = pass[r * 4 + w];
+                        s4[w] = (reach[r * 4 + w] | (r > 0 ? reach[r * 4 - 4 + w] : 0ull) | (r + 1 < H ? reach[r * 4 + 4 + w] : 0ull)) & p4[w];
+                    }
+                    fill_runs(p4, s4);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (s4[w] != reach[r * 4 + w]) { reach[r * 4 + w] = s4[w]; ch = true; }
+                }
+                if (ch) red[slot][2] = 1;
+                env_sync<NT>();
+                const uint32_t changed = red[slot][2];
+                env_sync<NT>();
+                if (!changed) break;
+            }
+            auto reached = [&](uint32_t x, uint32_t y) -> uint32_t { return (uint32_t)(reach[y * 4u + (x >> 6)] >> (x & 63u)) & 1u; };
+            for (uint32_t q = t; q < cells; q += NT) {
+                const uint32_t y = q / W, x = q - y * W;
+                uint32_t v = reached(x, y);
+                if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (src(q) & 0xffu) == (uint32_t)WF_DIRT_BURNING)     // reached iff a 4-neighbour is
+                    v = ((x > 0 && reached(x - 1, y)) || (x + 1 < W && reached(x + 1, y)) || (y > 0 && reached(x, y - 1)) || (y + 1 < H && reached(x, y + 1))) ? 1u : 0u;
+                reach_e[q] = (uint8_t)v;
+                if constexpr (STAGE) board[q] = (uint8_t)(v << 2);
+            }
+            env_sync<NT>();
+            valid = WF_F_REACH_VALID;
+        } else if (flood) {
+            // (grids wider than 256 cells, or too large for the bitmaps next to the byte board: cell-at-a-time relaxation)
             // border-reachability board of this environment, bits 0-1: 0 impassable, 1 passable, 3 passable + reached;
             // bit 2: the verdict the containment test reads (burning dirt: reached iff a 4-neighbour is)
             for (uint32_t q = t; q < cells; q += NT) {
@@ -1215,15 +1273,21 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         const bool cont = (a.hot_flags & WF_HOT_CONTAINMENT) != 0, wind = (a.hot_flags & WF_HOT_WIND) != 0;
         size_t aux = cont ? cells : 0;                                           // byte board
         if ((a.hot_flags & WF_HOT_RIVERS) && aux < (size_t)a.H * 2) aux = (size_t)a.H * 2;   // river row table
-        const size_t staged = (cells * 4 + aux + 15) & ~(size_t)15, plain = (aux + 15) & ~(size_t)15;
+        aux = (aux + 15) & ~(size_t)15;
         const bool wave = cells <= 1024;
+        // flood on two 256-bit bitmaps per row - for the workgroup-per-environment grids: up to 1 024 cells the
+        // cell-at-a-time relaxation of a wave is the faster one (65 536 x 15x15: 71 against 91 us per step)
+        size_t bm = (cont && a.W <= 256 && !wave) ? (size_t)a.H * 64 : 0;
         const unsigned epb = wave ? 4u : 1u;
-        const bool stage = staged * epb <= 20480;
-        const size_t slot = stage ? staged : plain;
+        const size_t words = (cells * 4 + 15) & ~(size_t)15;                     // the staged grid (16-byte granules, like every part)
+        const bool stage = (words + aux + bm) * epb <= 20480;
+        if (((stage ? words : 0) + aux + bm) * epb > 65536) bm = 0;
+        const size_t slot = (stage ? words : 0) + aux + bm;
+        const uint32_t bm_off = bm ? (uint32_t)(slot - bm) : 0u;
         unsigned blocks = (unsigned)((a.batch + epb - 1) / epb);
         if (blocks > 8192) blocks = 8192;
 #define WF_ENV_LAUNCH(NT, WIND, STAGE) \
-        hipLaunchKernelGGL((wf_step_env<NT, WIND, STAGE>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot)
+        hipLaunchKernelGGL((wf_step_env<NT, WIND, STAGE, NT == 256>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot, bm_off)
         if (wave) {
             if (wind) { if (stage) WF_ENV_LAUNCH(64, true, true); else WF_ENV_LAUNCH(64, true, false); }
             else { if (stage) WF_ENV_LAUNCH(64, false, true); else WF_ENV_LAUNCH(64, false, false); }
