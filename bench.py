@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline loop only: no fused / observation / host-API / single-launch / config legs (profiling passes)")
-    ap.add_argument("--legs", default="c2,c4,c5_shard,hbm_1m", help="extra config legs to run (comma separated)")
+    ap.add_argument("--legs", default="c2,c4,c5_shard,hbm_1m,c3_wind,mid_64", help="extra config legs to run (comma separated)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--ignite-ppm", type=int, default=0, help="extra pre-ignited cells per million at reset (config 4)")
@@ -213,12 +213,12 @@ class Stepper:
                 raise RuntimeError(f"wf_step_obs_device failed: {rc}")
 
 
-def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call=1, seed=1234, dev=None):
+def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call=1, seed=1234, dev=None, wind=None):
     """One extra config on this GPU: HIP-event time per call, cell-updates/s, its own roofline entry."""
     import torch
     from wildfire_control_python_amd import BatchedForestFire
     env = BatchedForestFire(B, size=S, device=dev.index, seed=seed, env_id0=env_id0, auto_reset=True,
-                            fuel_range=(10, 40), ignite_ppm=ppm)
+                            fuel_range=(10, 40), ignite_ppm=ppm, metadata={"wind": wind} if wind else None)
     env.reset(seed=seed)
     n = ticks_per_call
     rows = 1 if noop else 64
@@ -238,7 +238,7 @@ def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call
     us = ms / steps * 1e3
     achieved = BYTES_PER_CELL_UPDATE * cells * n / (us * 1e-6) / 1e9
     out = {"workload": f"{B} x {S}x{S}, fuel U{{10..40}}, " + ("no-op actions" if noop else "uniform N/S/E/W actions") +
-                       (f", {ppm} ppm pre-ignited" if ppm else "") + f", containment {'on' if env.containment else 'off'}, auto-reset"
+                       (f", {ppm} ppm pre-ignited" if ppm else "") + (f", wind {wind!r} (environment.py:187-193)" if wind else "") + f", containment {'on' if env.containment else 'off'}, auto-reset"
                        + (f", env ids from {env_id0}" if env_id0 else "") + f" ({config_label(S, B, noop, ppm)})",
            "calls": steps, "warmup": warmup, "ticks_per_call": n, "us_per_call": us,
            "cell_updates_per_s": cells * n * steps / (ms * 1e-3),
@@ -430,6 +430,10 @@ def main():
             "c4": dict(S=256, B=1024, noop=True, ppm=10000, steps=200, warmup=20),
             "c5_shard": dict(S=14, B=125000, noop=False, env_id0=875000, steps=400, warmup=40),
             "hbm_1m": dict(S=14, B=1048576, noop=False, steps=120, warmup=20),
+            # informational (no BASELINE config): the reference's off-by-default wind option at the headline size (generic
+            # kernel family), and a mid-size grid (tiled family, strips packed four per wave)
+            "c3_wind": dict(S=14, B=65536, noop=False, steps=200, warmup=20, wind="random"),
+            "mid_64": dict(S=64, B=4096, noop=False, steps=200, warmup=20),
         }
         for nm in want:
             if nm in specs:

@@ -306,9 +306,10 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     // wind with a direction is served by the thread-per-cell family, whatever the shape
     // (WF_FAMILY=cells / tiled, experiments and tests: the generic family for a shape another family would serve, the
     // tiled family for a small grid)
-    const char *force = getenv("WF_FAMILY");
-    WfFamily fam = (pp.wind_mode != WF_WIND_CALM || (force && !strcmp(force, "cells"))) ? WF_FAM_CELLS : wf_pick_family(H, W);
-    if (force && !strcmp(force, "tiled") && fam == WF_FAM_CELLS && pp.wind_mode == WF_WIND_CALM && wf_tiled_serves(H, W)) fam = WF_FAM_TILED;
+    WfKnobs kn0;
+    wf_read_knobs(&kn0);
+    WfFamily fam = (pp.wind_mode != WF_WIND_CALM || kn0.family == 1) ? WF_FAM_CELLS : wf_pick_family(H, W);
+    if (kn0.family == 2 && fam == WF_FAM_CELLS && pp.wind_mode == WF_WIND_CALM && wf_tiled_serves(H, W)) fam = WF_FAM_TILED;
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
     // the wave kernels address the planes with 32-bit byte offsets
     if (fam == WF_FAM_WAVE && (unsigned long long)batch * H * W * 4ull > 0xFFFFFFFFull) return WF_ERR_UNSUPPORTED;
@@ -343,7 +344,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         c->own_stream = true;
         if ((e = hipEventCreate(&c->ev0)) != hipSuccess) break;
         if ((e = hipEventCreate(&c->ev1)) != hipSuccess) break;
-        wf_read_knobs(&c->knobs);
+        c->knobs = kn0;
         c->n_parts = c->knobs.n_parts < 1 ? 1 : c->knobs.n_parts > WF_MAX_SIDE + 1 ? WF_MAX_SIDE + 1 : c->knobs.n_parts;
         for (int i = 0; i < c->n_parts - 1 && e == hipSuccess; ++i) {
             if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) break;

@@ -71,6 +71,7 @@ struct WfKnobs {
     int rows;        // WF_ROWS: keep the rows layout for group overrides beyond 16
     int no_rows;     // WF_NO_ROWS: 4-cells-per-lane group layout only
     int no_multi;    // WF_NO_MULTI: an n-step call of a large batch = n single-step launches
+    int family;       // WF_FAMILY=cells (1) / tiled (2): kernel family override, honoured by wf_create only
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
     int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop

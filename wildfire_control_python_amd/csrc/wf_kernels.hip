@@ -31,6 +31,7 @@
 //     one write of the grid per launch.
 //
 // No MFMA anywhere: the path is HBM-bound byte work, not a contraction.
+#include <string.h>
 #include <utility>
 
 #include "wf_device.h"
@@ -448,6 +449,8 @@ void wf_read_knobs(WfKnobs *k)
     k->no_multi = set("WF_NO_MULTI");
     k->multi_small = set("WF_MULTI_SMALL");
     k->cells_legacy = set("WF_CELLS_LEGACY");
+    const char *fam = getenv("WF_FAMILY");
+    k->family = !fam ? 0 : !strcmp(fam, "cells") ? 1 : !strcmp(fam, "tiled") ? 2 : 0;
     k->multi_rows = 0;
 }
 

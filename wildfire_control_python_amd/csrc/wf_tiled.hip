@@ -630,6 +630,40 @@ __device__ __forceinline__ void fill_runs(const u64 (&p)[4], u64 (&s)[4])
     for (int w = 0; w < 4; ++w) s[w] = up[w] | dn[w];
 }
 
+// Relaxation of a border-reachability board kept as linear row bitmaps (256 bits per row: pass = passable cells, reach =
+// seeds on entry, the flood on return), by `nthreads` threads of which this is thread `t`: one thread per row takes what
+// the rows above and below have reached, then fills along the row's passable runs in both directions.  A sweep advances a
+// whole horizontal run and one row, so the open field outside a dug ring converges in two or three sweeps; `bound`
+// (H*W) sweeps always suffice.  `changed`: an LDS word of the group; `sync`: its barrier.  Returns true when converged.
+template <class Sync>
+__device__ __forceinline__ bool relax_row_bitmaps(const u64 *pass, u64 *reach, uint32_t H, uint32_t bound, uint32_t t, uint32_t nthreads,
+                                                  uint32_t *changed, Sync sync)
+{
+    for (uint32_t it = 0; it < bound; ++it) {
+        if (t == 0) *changed = 0;
+        sync();
+        bool ch = false;
+        for (uint32_t r = t; r < H; r += nthreads) {
+            u64 p4[4], s4[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                p4[w] = pass[r * 4 + w];
+                s4[w] = (reach[r * 4 + w] | (r > 0 ? reach[r * 4 - 4 + w] : 0ull) | (r + 1 < H ? reach[r * 4 + 4 + w] : 0ull)) & p4[w];
+            }
+            fill_runs(p4, s4);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (s4[w] != reach[r * 4 + w]) { reach[r * 4 + w] = s4[w]; ch = true; }
+        }
+        if (ch) *changed = 1;
+        sync();
+        const uint32_t any = *changed;
+        sync();
+        if (!any) return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------- prologue of a tiled step
 // One workgroup per environment does everything that has to precede the in-place tick, in ONE launch (it used to be
 // three: each kernel boundary of a step costs ~4.5 us that nothing overlaps):
@@ -681,36 +715,7 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
             }
         }
         __syncthreads();
-        // Relaxation, one thread per row: take what the rows above and below have reached, then fill along the row's
-        // passable runs in both directions at once (a carry runs through a run of ones: fill_runs).  A sweep so advances
-        // a whole horizontal run and one row per step; the open field outside a dug ring converges in two or three
-        // sweeps where the cell-by-cell relaxation needed as many as the grid is wide.  H*W sweeps always suffice.
-        bool converged = false;
-        for (uint32_t it = 0; it < H * W; ++it) {
-            if (threadIdx.x == 0) changed = 0;
-            __syncthreads();
-            bool ch = false;
-            for (uint32_t r = threadIdx.x; r < H; r += 256u) {
-                u64 p[4], s4[4];
-                bool grew = false;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    p[w] = pass[r * 4 + w];
-                    const u64 cur = reach[r * 4 + w];
-                    s4[w] = (cur | (r > 0 ? reach[r * 4 - 4 + w] : 0ull) | (r + 1 < H ? reach[r * 4 + 4 + w] : 0ull)) & p[w];
-                }
-                fill_runs(p, s4);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    if (s4[w] != reach[r * 4 + w]) { reach[r * 4 + w] = s4[w]; grew = true; }
-                }
-                ch |= grew;
-            }
-            if (ch) changed = 1;
-            __syncthreads();
-            if (!changed) { converged = true; break; }
-            __syncthreads();
-        }
+        const bool converged = relax_row_bitmaps(pass, reach, H, H * W, threadIdx.x, 256u, &changed, [] { __syncthreads(); });
         // back to the tick's interleaved layout, in place: component j of row r = every fourth bit from bit j
         __syncthreads();
         for (uint32_t r = threadIdx.x; r < H; r += 256u) {
@@ -1026,28 +1031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
                 reach[k] = mk & seeds;
             }
             env_sync<NT>();
-            for (uint32_t it = 0; it < cells; ++it) {
-                if (t == 0) red[slot][2] = 0;
-                env_sync<NT>();
-                bool ch = false;
-                for (uint32_t r = t; r < H; r += NT) {
-                    u64 p4[4], s4[4];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        p4[w] = pass[r * 4 + w];
-                        s4[w] = (reach[r * 4 + w] | (r > 0 ? reach[r * 4 - 4 + w] : 0ull) | (r + 1 < H ? reach[r * 4 + 4 + w] : 0ull)) & p4[w];
-                    }
-                    fill_runs(p4, s4);
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        if (s4[w] != reach[r * 4 + w]) { reach[r * 4 + w] = s4[w]; ch = true; }
-                }
-                if (ch) red[slot][2] = 1;
-                env_sync<NT>();
-                const uint32_t changed = red[slot][2];
-                env_sync<NT>();
-                if (!changed) break;
-            }
+            relax_row_bitmaps(pass, reach, H, cells, t, (uint32_t)NT, &red[slot][2], [] { env_sync<NT>(); });
             auto reached = [&](uint32_t x, uint32_t y) -> uint32_t { return (uint32_t)(reach[y * 4u + (x >> 6)] >> (x & 63u)) & 1u; };
             for (uint32_t q = t; q < cells; q += NT) {
                 const uint32_t y = q / W, x = q - y * W;
