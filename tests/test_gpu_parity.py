@@ -172,7 +172,8 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               (50, 42, 520), (11, 11, -128), (30, 23, -48), (15, 15, 700),
               # small grids the tiled family can serve go to the generic one (faster below 32x32); WF_FAMILY=tiled keeps
               # the tiled kernels covered there (marked by B + 10000); packed strips: 4 per wave up to W = 64, 2 up to 128
-              (24, 24, 10096), (32, 20, 10064), (48, 48, 24), (64, 100, 12), (128, 128, 6), (36, 30, 40)]
+              (24, 24, 10096), (32, 20, 10064), (48, 48, 24), (64, 100, 12), (128, 128, 6), (36, 30, 40),
+              (64, 300, 6), (128, 200, 4), (100, 140, 4)]          # packed strips AND several workgroups per environment
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)

@@ -106,7 +106,7 @@ def test_reset_with_rivers_oracle_layout():
 
 # ----------------------------------------------------------------------------- HIP
 @pytest.mark.gpu
-@pytest.mark.parametrize("W,H,B", [(14, 14, 20000), (10, 10, 20000), (12, 12, 3000), (20, 10, 3000), (24, 16, 600), (13, 11, 600), (256, 64, 8), (42, 30, 520)])
+@pytest.mark.parametrize("W,H,B", [(14, 14, 20000), (10, 10, 20000), (12, 12, 3000), (20, 10, 3000), (24, 16, 600), (13, 11, 600), (256, 64, 8), (42, 30, 520), (64, 48, 200), (100, 150, 12)])
 def test_device_reset_with_rivers_equals_oracle(monkeypatch, W, H, B):
     """make_rivers on the device: wf_reset and the in-kernel auto-reset draw the river from the counter-based stream,
     bit-equal to the oracle in every kernel family (rows / group / fused wave kernels, tiled, generic)."""
