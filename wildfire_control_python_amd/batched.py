@@ -193,13 +193,14 @@ class BatchedForestFire:
         (apply_heat_from_to, environment.py:278-287)."""
         import math
         speed, vec = self.winds(envs)
-        out = np.empty((self.batch, 4))
-        for k, (cx, cy) in enumerate(((0, -1), (0, 1), (1, 0), (-1, 0))):
-            for b in range(self.batch):
-                wx, wy = vec[b]
-                angle = abs(math.atan2(wx * cy - wy * cx, wx * cx + wy * cy))
-                out[b, k] = speed[b] * grass["heat"] * (angle + 1) ** (-1)
-        return out
+        # the factor (angle + distance)**-1 of every wind vector and direction: 9 x 4 values, then a table look-up
+        factor = np.empty((3, 3, 4))
+        for wx in (-1, 0, 1):
+            for wy in (-1, 0, 1):
+                for k, (cx, cy) in enumerate(((0, -1), (0, 1), (1, 0), (-1, 0))):
+                    angle = abs(math.atan2(wx * cy - wy * cx, wx * cx + wy * cy))
+                    factor[wx + 1, wy + 1, k] = (angle + 1) ** (-1)
+        return (speed * grass["heat"])[:, None] * factor[vec[:, 0] + 1, vec[:, 1] + 1]
 
     def download_envs(self):
         """Only the per-environment records (16 B each): agent position, flags, episode, tick."""

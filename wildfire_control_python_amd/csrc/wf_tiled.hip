@@ -1,21 +1,23 @@
-// wf_tiled.hip - gfx950 kernels for grids that do not fit one wavefront (e.g. 256x256).
+// wf_tiled.hip - gfx950 kernels for grids that do not fit one wavefront (e.g. 256x256), and the generic family.
 //
 // Same rule as wf_kernels.hip (synchronous integer restatement of
 // Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step of the TILED family
-// (W % 4 == 0, W <= 256) is two launches:
+// (W % 4 == 0, W <= 256, at least 1 024 cells) is two launches:
 //   wf_tiled_prologue   one workgroup per environment: Agent.move / toggle / death (environment.py:116-171) with
 //                       the dug cell and the agent_pos bytes written straight into the grid; the border-reachability
-//                       flood when a dig may have cut a region off; the still-burning masks of the rows between the
-//                       workgroups of the tick (it runs in place)
+//                       flood when a dig may have cut a region off (run fill on linear row bitmaps, relax_row_bitmaps);
+//                       the still-burning masks of the rows between the workgroups of the tick (it runs in place)
 //   wf_step_tiled       the CA tick in place (+ the observation, when asked for; + the fresh rows of environments that
 //                       are being auto-reset); per-env reductions by atomics, and the last of an environment's
 //                       workgroups to arrive does World.RUNNING, reward, done, record
 // (wf_reset: wf_big_reset_rec -> wf_big_reset_cells)
-// and of the GENERIC family (any shape, thread per cell, ping-pong planes):
-//   wf_big_pre -> [wf_big_reset_cells] -> [wf_cells_flood] -> wf_step_cells -> wf_big_post
+// and of the GENERIC family (any shape, wind with a direction, small grids; ping-pong planes):
+//   wf_big_pre -> wf_step_env      a wave (up to 1 024 cells) or a workgroup per environment: reset / flood / tick / reward
+//   (few huge grids, WF_CELLS_LEGACY=1: wf_big_pre -> [wf_big_reset_cells] -> [wf_cells_flood] -> wf_step_cells -> wf_big_post)
 //
-// wf_step_tiled: a workgroup = 4 waves = 4 vertically adjacent strips of TR rows of one
-// environment.  A wave sweeps its strip top to bottom; lane l owns cells x = 4l..4l+3 of
+// wf_step_tiled: a workgroup = up to 4 waves = vertically adjacent strips of TR rows of one
+// environment (grids narrower than 128 cells: 2 or 4 strips side by side per wave, struct Pack).
+// A wave sweeps its strip top to bottom; lane l owns cells x = 4l..4l+3 of
 // the current row (one coalesced dwordx4 per lane, a 256-wide row = one 1 KiB wave load).
 // "Still burning" becomes four 64-bit lane masks per row (wavefront ballot).  The vertical
 // neighbours of a cell are THE SAME BIT of the masks of the rows above and below, the
