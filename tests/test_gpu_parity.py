@@ -1123,6 +1123,41 @@ def test_full_size_every_environment_matches_oracle(wf):
     env.close()
 
 
+def test_full_size_wind_random_matches_oracle(wf):
+    """The headline size with METADATA['wind'] = "random": 65 536 x 14x14 on the generic family, as two shares of the
+    batch on two streams (12.8 M cells), auto-reset, containment: every environment against the oracle - rewards and
+    done flags each step, planes, records, wind codes and per-direction heat counts at the end."""
+    from tests.golden_util import WIND_SPEEDS
+    B, S, T = 65536, 14, 30
+    env = wf.BatchedForestFire(B, size=S, seed=5, auto_reset=True, containment=True, fuel_range=(3, 25), ignite_ppm=3000,
+                               metadata={"wind": "random"})
+    assert env.step_launches == 2 and env.step_kernel == "wf_step_env"
+    env.reset(seed=5)
+    op = O.default_params(containment=1, fuel_lo=3, fuel_hi=25, ignite_ppm=3000, wind_mode=2, wind_speeds=WIND_SPEEDS + [0.0])
+    planes, envs = O.new_state(B, S, S)
+    counts = np.zeros(planes.shape, np.uint8)
+    O.reset(planes, envs, seed=5, params=op, counts=counts)
+    rng = np.random.default_rng(5)
+    resets = 0
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        _, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op, counts=counts)
+        if stopped.any():
+            O.reset(planes, envs, seed=5, mask=stopped, params=op, counts=counts)
+            ro[stopped], do[stopped] = 0.0, 0
+            resets += int(stopped.sum())
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+    gp, ge = env.download()
+    np.testing.assert_array_equal(gp, planes)
+    np.testing.assert_array_equal(_envs(ge), envs)
+    np.testing.assert_array_equal(env.download_counts(), counts)
+    assert resets > B // 4            # a third of the winds has speed 0: the fire dies where it started
+    env.close()
+
+
 @pytest.mark.parametrize("algo", ["DQN", "SARSA", "DDQN", "DSARSA"])
 def test_batched_learner_runs_on_the_device_api(wf, algo):
     """The four value-based learners of the reference, batched, drive the env through
