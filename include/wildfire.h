@@ -159,7 +159,9 @@ int wf_wind_counts_upload(wf_ctx *ctx, const uint8_t *counts);
 int wf_wind_counts_download(wf_ctx *ctx, uint8_t *counts);
 
 /* World.reset() (environment.py:186-212) for envs with mask[i] != 0 (NULL = all), spawn
- * drawn from the counter-based stream keyed by (seed, env_id0 + i, episode). */
+ * drawn from the counter-based stream keyed by (seed, env_id0 + i, episode).  Grids smaller than 7 cells in either
+ * direction cannot hold the spawn circle (the reference asserts 10x10, utility.py:68): WF_ERR_UNSUPPORTED, also for
+ * auto_reset; such grids can still be uploaded and stepped. */
 int wf_reset(wf_ctx *ctx, const uint8_t *mask, uint64_t seed);
 int wf_reset_device(wf_ctx *ctx, const uint8_t *d_mask, uint64_t seed);
 

@@ -592,6 +592,8 @@ int wfo_reset(int batch, int H, int W, int8_t *planes, wfo_env *envs,
     int cdx[3][32], cdy[3][32], cn[3];
     if (batch < 0 || H <= 0 || W <= 0 || !planes || !envs || !p)
         return -1;
+    if (H < 7 || W < 7)          /* the spawn circle of radius 3 must fit (the reference asserts 10x10, utility.py:68) */
+        return -1;
     if (!world_alloc(&w, H, W, p)) {
         world_free(&w);
         return -1;

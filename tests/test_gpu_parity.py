@@ -1277,6 +1277,14 @@ def test_api_edge_cases(wf):
     p = N.default_params()
     assert lib.wf_create(ctypes.byref(h), 99, 4, 10, 10, ctypes.byref(p)) == -1
     assert lib.wf_create(ctypes.byref(h), 0, 4, 0, 10, ctypes.byref(p)) == -1
+    # a grid that cannot hold the spawn circle (radius 3 around the centre): steps, but neither resets nor auto-resets
+    assert lib.wf_create(ctypes.byref(h), 0, 4, 6, 9, ctypes.byref(p)) == 0
+    assert lib.wf_reset(h, None, ctypes.c_uint64(1)) == -2
+    assert lib.wf_step(h, None, 1, ctypes.c_uint64(1), None, None) == 0
+    p.auto_reset = 1
+    assert lib.wf_set_params(h, ctypes.byref(p)) == -2
+    assert lib.wf_destroy(h) == 0
+    assert lib.wf_create(ctypes.byref(h), 0, 4, 9, 6, ctypes.byref(p)) == -2
 
 
 def test_external_stream_and_timer(wf):
@@ -1398,6 +1406,7 @@ def _random_state(B, H, W, rng, toggle):
     kinds = [0, 1, 2, 3, 4] + ([5, 6] if toggle else [])
     probs = np.array([0.62, 0.10, 0.08, 0.08, 0.06] + ([0.03, 0.03] if toggle else []))
     t = rng.choice(kinds, size=(B, H, W), p=probs / probs.sum()).astype(np.int8)
+    t[:, 0, 0] = np.where(t[:, 0, 0] == 4, 0, t[:, 0, 0])          # (a place for the agent even on a 1x1 grid)
     fuel = rng.integers(1, 45, size=(B, H, W))
     burning = (t == 1) | (t == 5)
     fuel[burning] = rng.integers(-3, 30, size=int(burning.sum()))     # <= 0: poked states only, burn out at once
@@ -1421,7 +1430,10 @@ def _random_state(B, H, W, rng, toggle):
 
 
 @pytest.mark.parametrize("W,H,toggle", [(14, 14, False), (10, 10, True), (12, 12, True), (16, 8, False), (24, 16, True),
-                                        (64, 70, False), (11, 13, True)])
+                                        (64, 70, False), (11, 13, True),
+                                        # grids too small for World.reset()'s spawn circle: uploaded states only
+                                        (5, 4, True), (3, 3, False), (1, 6, False), (6, 1, True), (2, 9, False), (1, 1, False),
+                                        (4, 4, True), (40, 3, False), (36, 30, True), (100, 70, True), (51, 47, False)])
 def test_arbitrary_uploaded_states_match_oracle(wf, W, H, toggle):
     """Parity on states no reset would produce (uploaded through wf_upload): every kernel family, with and without
     the dig toggle, 40 steps of random actions from each of several random states."""

@@ -89,6 +89,9 @@ def test_bad_arguments_rejected_before_touching_a_device():
     assert lib.wf_create(ctypes.byref(h), 0, 0, 14, 14, ctypes.byref(p)) == -1       # batch 0
     assert lib.wf_create(ctypes.byref(h), 0, 1, 301, 301, ctypes.byref(p)) == -2     # containment beyond the generic flood board
     assert lib.wf_create(ctypes.byref(h), 0, 1, 1100, 8, ctypes.byref(p)) == -2      # ... and beyond the tiled one (H > 1024)
+    p.auto_reset = 1
+    assert lib.wf_create(ctypes.byref(h), 0, 4, 6, 14, ctypes.byref(p)) == -2        # auto-reset on a grid too small for the spawn circle
+    p.auto_reset = 0
     p.ignite_count = 0
     assert lib.wf_create(ctypes.byref(h), 0, 4, 14, 14, ctypes.byref(p)) == -1
     assert lib.wf_step(None, None, 1, 1, None, None) == -1

@@ -108,6 +108,10 @@ bool params_ok(const wf_params *p)
     return true;
 }
 
+// World.reset() puts the agent on a circle of radius 1..3 around the centre (utility.py:66-78; the reference asserts
+// grids of at least 10x10, utility.py:68): a grid must hold that circle.  Smaller grids can still be uploaded and stepped.
+bool reset_ok(int H, int W) { return H >= 7 && W >= 7; }
+
 // reset_map's river needs room for its margins (the reference asserts grids of at least 10x10, utility.py:68) and, in
 // the big-grid families, a row table in LDS
 bool rivers_ok(WfFamily fam, int H, int W)
@@ -318,6 +322,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (fam == WF_FAM_TILED && pp.containment && H > 1024) return WF_ERR_UNSUPPORTED;   // boards live in LDS (64 KiB)
     if (fam != WF_FAM_WAVE && (unsigned long long)H * W > 0xFFFFull * 0xFFFFull) return WF_ERR_UNSUPPORTED;
     if (pp.make_rivers && !rivers_ok(fam, H, W)) return WF_ERR_UNSUPPORTED;
+    if (pp.auto_reset && !reset_ok(H, W)) return WF_ERR_UNSUPPORTED;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return WF_ERR_NO_DEVICE;
@@ -424,6 +429,7 @@ int wf_set_params(wf_ctx *c, const wf_params *p)
     if (c->fam == WF_FAM_CELLS && p->containment && (long long)c->H * c->W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
     if (p->make_rivers && !rivers_ok(c->fam, c->H, c->W)) return WF_ERR_UNSUPPORTED;
+    if (p->auto_reset && !reset_ok(c->H, c->W)) return WF_ERR_UNSUPPORTED;
     // the kernel family and the count plane were chosen in wf_create
     if ((p->wind_mode != WF_WIND_CALM) != (c->p.wind_mode != WF_WIND_CALM)) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -507,6 +513,7 @@ int wf_wind_counts_download(wf_ctx *c, uint8_t *counts)
 int wf_reset_device(wf_ctx *c, const uint8_t *d_mask, uint64_t seed)
 {
     if (!c) return WF_ERR_ARG;
+    if (!reset_ok(c->H, c->W)) return WF_ERR_UNSUPPORTED;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     WfArgs a = base_args(c);
