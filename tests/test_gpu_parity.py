@@ -135,6 +135,46 @@ def test_wind_step_and_reset_match_oracle(wf, W, H, wind, auto, B):
     env.close()
 
 
+def test_wind_with_rivers_and_dig_toggle(wf):
+    """All three off-by-default options of the reference at once (constants.py:39,44,46): random wind, rivers, dig
+    toggle, plus auto-reset and containment - generic family against the oracle, every step."""
+    from tests.golden_util import WIND_SPEEDS
+    from wildfire_control_python_amd import _native as N
+    B, T, W, H = 640, 120, 14, 12
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=9, fuel_range=(5, 20), auto_reset=True,
+                               metadata={"wind": "random", "make_rivers": True, "allow_dig_toggle": True, "n_actions": 5})
+    op = O.default_params(fuel_lo=5, fuel_hi=20, wind_mode=2, wind_speeds=WIND_SPEEDS + [0.0], make_rivers=1, allow_dig_toggle=1)
+    env.reset(seed=3)
+    planes, envs = O.new_state(B, H, W)
+    counts = np.zeros(planes.shape, np.uint8)
+    O.reset(planes, envs, seed=3, params=op, counts=counts)
+    rng = np.random.default_rng(1)
+    seen5 = 0
+    for t in range(T):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        obs, r, d, _ = env.step(a)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a, op, counts=counts)
+        if stopped.any():
+            O.reset(planes, envs, seed=9, mask=stopped, params=op, counts=counts)
+            ro[stopped], do[stopped] = 0.0, 0
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs t={t}")
+        np.testing.assert_array_equal(env.download_counts(), counts, err_msg=f"counts t={t}")
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
+        seen5 += int((planes[..., 0] == 5).sum())
+    assert (planes[..., 0] == 4).any() and seen5 > 0
+    env.close()
+    # the count plane exists only with a wind that has a direction
+    calm = wf.BatchedForestFire(4, size=10)
+    buf = np.zeros((4, 10, 10, 4), np.uint8)
+    assert calm._lib.wf_wind_counts_download(calm._h, N.ptr(buf)) == -2 and calm._lib.wf_wind_counts_upload(calm._h, N.ptr(buf)) == -2
+    calm.close()
+
+
 def test_wind_adapter_draws_like_the_reference(wf):
     """METADATA['wind'] = "random" through the single-environment adapter: a seeded reset draws the wind speed from
     numpy's stream and the vector from Python's, before the spawn point, as World.reset does (environment.py:188-190);
