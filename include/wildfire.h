@@ -146,7 +146,8 @@ int wf_set_params(wf_ctx *ctx, const wf_params *p);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int wf_set_stream(wf_ctx *ctx, void *hip_stream);
 
-/* Host <-> device state exchange (synchronous).  Either pointer may be NULL to skip it.
+/* Host <-> device state exchange (synchronous).  Either pointer may be NULL to skip it.  A record whose agent position
+ * lies outside the grid is refused (WF_ERR_ARG, nothing uploaded).
  * replaces: direct numpy access to World.env (environment.py:38-50) */
 int wf_upload(wf_ctx *ctx, const int8_t *planes, const wf_env *envs);
 int wf_download(wf_ctx *ctx, int8_t *planes, wf_env *envs);

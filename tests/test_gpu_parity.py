@@ -1317,6 +1317,19 @@ def test_api_edge_cases(wf):
     p = N.default_params()
     assert lib.wf_create(ctypes.byref(h), 99, 4, 10, 10, ctypes.byref(p)) == -1
     assert lib.wf_create(ctypes.byref(h), 0, 4, 0, 10, ctypes.byref(p)) == -1
+    # a record pointing outside the grid is refused, nothing is uploaded
+    env = wf.BatchedForestFire(5, size=10)
+    env.reset(seed=1)
+    gp, ge = env.download()
+    bad = ge.copy()
+    bad["x"][3] = 10
+    assert lib.wf_upload(env._h, None, N.ptr(bad)) == -1
+    bad["x"][3], bad["y"][0] = 0, 200
+    assert lib.wf_upload(env._h, N.ptr(np.zeros_like(gp)), N.ptr(bad)) == -1
+    gp2, ge2 = env.download()
+    np.testing.assert_array_equal(gp2, gp)
+    np.testing.assert_array_equal(ge2, ge)
+    env.close()
     # a grid that cannot hold the spawn circle (radius 3 around the centre): steps, but neither resets nor auto-resets
     assert lib.wf_create(ctypes.byref(h), 0, 4, 6, 9, ctypes.byref(p)) == 0
     assert lib.wf_reset(h, None, ctypes.c_uint64(1)) == -2

@@ -457,6 +457,11 @@ int wf_set_stream(wf_ctx *c, void *hip_stream)
 int wf_upload(wf_ctx *c, const int8_t *planes, const wf_env *envs)
 {
     if (!c) return WF_ERR_ARG;
+    // the kernels address cells through the agent's position: a record that points outside the grid is refused here
+    // (like the reference's binding, pyastar.py:27-37, which validates before it calls into native code)
+    if (envs)
+        for (int i = 0; i < c->batch; ++i)
+            if (envs[i].x >= c->W || envs[i].y >= c->H) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     const size_t cells = (size_t)c->batch * c->H * c->W;
