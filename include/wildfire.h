@@ -147,7 +147,8 @@ int wf_set_params(wf_ctx *ctx, const wf_params *p);
 int wf_set_stream(wf_ctx *ctx, void *hip_stream);
 
 /* Host <-> device state exchange (synchronous).  Either pointer may be NULL to skip it.  A record whose agent position
- * lies outside the grid is refused (WF_ERR_ARG, nothing uploaded).
+ * lies outside the grid, or a cell type outside 0..4 (0..6 with allow_dig_toggle), is refused (WF_ERR_ARG, nothing
+ * uploaded).
  * replaces: direct numpy access to World.env (environment.py:38-50) */
 int wf_upload(wf_ctx *ctx, const int8_t *planes, const wf_env *envs);
 int wf_download(wf_ctx *ctx, int8_t *planes, wf_env *envs);

@@ -1326,6 +1326,11 @@ def test_api_edge_cases(wf):
     assert lib.wf_upload(env._h, None, N.ptr(bad)) == -1
     bad["x"][3], bad["y"][0] = 0, 200
     assert lib.wf_upload(env._h, N.ptr(np.zeros_like(gp)), N.ptr(bad)) == -1
+    weird = gp.copy()
+    weird[2, 3, 4, 0] = 5                                # burning dirt: a code only allow_dig_toggle knows
+    assert lib.wf_upload(env._h, N.ptr(weird), None) == -1
+    weird[2, 3, 4, 0] = -1
+    assert lib.wf_upload(env._h, N.ptr(weird), N.ptr(ge)) == -1
     gp2, ge2 = env.download()
     np.testing.assert_array_equal(gp2, gp)
     np.testing.assert_array_equal(ge2, ge)

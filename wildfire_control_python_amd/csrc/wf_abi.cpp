@@ -6,6 +6,7 @@
 // usable HIP device wf_create fails with WF_ERR_NO_DEVICE.
 #include <math.h>
 #include <new>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -462,6 +463,19 @@ int wf_upload(wf_ctx *c, const int8_t *planes, const wf_env *envs)
     if (envs)
         for (int i = 0; i < c->batch; ++i)
             if (envs[i].x >= c->W || envs[i].y >= c->H) return WF_ERR_ARG;
+    // ... and so is a cell type the kernels do not know (codes 5 / 6 exist only with allow_dig_toggle, see wildfire.h)
+    if (planes) {
+        const size_t n = (size_t)c->batch * c->H * c->W;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(planes);
+        const uint32_t top = c->p.allow_dig_toggle ? (uint32_t)WF_BURNT_BLOCKED : (uint32_t)WF_WATER;
+        uint32_t bad = 0;
+        if ((reinterpret_cast<uintptr_t>(planes) & 3u) == 0) {
+            for (size_t i = 0; i < n; ++i) bad |= (w[i] & 0xffu) > top ? 1u : 0u;
+        } else {
+            for (size_t i = 0; i < n; ++i) bad |= (uint32_t)(uint8_t)planes[4 * i] > top ? 1u : 0u;
+        }
+        if (bad) return WF_ERR_ARG;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     const size_t cells = (size_t)c->batch * c->H * c->W;
