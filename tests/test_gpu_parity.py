@@ -1181,7 +1181,7 @@ def test_full_size_wind_random_matches_oracle(wf):
     resets = 0
     for t in range(T):
         a = rng.integers(0, 6, size=B).astype(np.int8)
-        _, r, d, _ = env.step(a)
+        obs, r, d, _ = env.step(a)
         stopped = (envs["flags"] & O.F_RUNNING) == 0
         ro, do = O.step(planes, envs, a, op, counts=counts)
         if stopped.any():
@@ -1190,6 +1190,8 @@ def test_full_size_wind_random_matches_oracle(wf):
             resets += int(stopped.sum())
         np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
         np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        if t % 10 == 9:          # the observation kernel runs behind each share's step, on the share's own stream
+            np.testing.assert_array_equal(obs, O.get_state(planes), err_msg=f"obs t={t}")
     gp, ge = env.download()
     np.testing.assert_array_equal(gp, planes)
     np.testing.assert_array_equal(_envs(ge), envs)
