@@ -605,15 +605,16 @@ __device__ __forceinline__ u64 squeeze4(u64 v)
     return v;
 }
 
-// Flood the seeds s (a subset of p) along the runs of ones of the 256-bit row p, towards both ends: adding a seed to
-// its run carries through the rest of the run, so (p ^ (p + s)) & p is everything from a seed up to the run's end;
-// the same on the bit-reversed row fills downwards.
-__device__ __forceinline__ void fill_runs(const u64 (&p)[4], u64 (&s)[4])
+// Flood the seeds s (a subset of p) along the runs of ones of the row bitmap p (NW words of 64 bits), towards both ends:
+// adding a seed to its run carries through the rest of the run, so (p ^ (p + s)) & p is everything from a seed up to
+// the run's end; the same on the bit-reversed row fills downwards.
+template <int NW>
+__device__ __forceinline__ void fill_runs(const u64 (&p)[NW], u64 (&s)[NW])
 {
-    u64 up[4], dn[4];
+    u64 up[NW], dn[NW];
     unsigned char carry = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const u64 t = p[w] + s[w], t2 = t + carry;
         const unsigned char c2 = (t < p[w]) | (t2 < t);
         up[w] = ((p[w] ^ t2) & p[w]) | s[w];
@@ -621,23 +622,23 @@ __device__ __forceinline__ void fill_runs(const u64 (&p)[4], u64 (&s)[4])
     }
     carry = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {                       // reversed row: word 3 - w, bits reversed
-        const u64 pr = __brevll(p[3 - w]), sr = __brevll(s[3 - w]);
+    for (int w = 0; w < NW; ++w) {                      // reversed row: word NW-1 - w, bits reversed
+        const u64 pr = __brevll(p[NW - 1 - w]), sr = __brevll(s[NW - 1 - w]);
         const u64 t = pr + sr, t2 = t + carry;
         const unsigned char c2 = (t < pr) | (t2 < t);
-        dn[3 - w] = __brevll(((pr ^ t2) & pr) | sr);
+        dn[NW - 1 - w] = __brevll(((pr ^ t2) & pr) | sr);
         carry = c2;
     }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s[w] = up[w] | dn[w];
+    for (int w = 0; w < NW; ++w) s[w] = up[w] | dn[w];
 }
 
-// Relaxation of a border-reachability board kept as linear row bitmaps (256 bits per row: pass = passable cells, reach =
+// Relaxation of a border-reachability board kept as linear row bitmaps (NW words per row: pass = passable cells, reach =
 // seeds on entry, the flood on return), by `nthreads` threads of which this is thread `t`: one thread per row takes what
 // the rows above and below have reached, then fills along the row's passable runs in both directions.  A sweep advances a
 // whole horizontal run and one row, so the open field outside a dug ring converges in two or three sweeps; `bound`
 // (H*W) sweeps always suffice.  `changed`: an LDS word of the group; `sync`: its barrier.  Returns true when converged.
-template <class Sync>
+template <int NW, class Sync>
 __device__ __forceinline__ bool relax_row_bitmaps(const u64 *pass, u64 *reach, uint32_t H, uint32_t bound, uint32_t t, uint32_t nthreads,
                                                   uint32_t *changed, Sync sync)
 {
@@ -646,16 +647,16 @@ __device__ __forceinline__ bool relax_row_bitmaps(const u64 *pass, u64 *reach, u
         sync();
         bool ch = false;
         for (uint32_t r = t; r < H; r += nthreads) {
-            u64 p4[4], s4[4];
+            u64 p4[NW], s4[NW];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                p4[w] = pass[r * 4 + w];
-                s4[w] = (reach[r * 4 + w] | (r > 0 ? reach[r * 4 - 4 + w] : 0ull) | (r + 1 < H ? reach[r * 4 + 4 + w] : 0ull)) & p4[w];
+            for (int w = 0; w < NW; ++w) {
+                p4[w] = pass[r * NW + w];
+                s4[w] = (reach[r * NW + w] | (r > 0 ? reach[(r - 1u) * NW + w] : 0ull) | (r + 1 < H ? reach[(r + 1u) * NW + w] : 0ull)) & p4[w];
             }
-            fill_runs(p4, s4);
+            fill_runs<NW>(p4, s4);
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                if (s4[w] != reach[r * 4 + w]) { reach[r * 4 + w] = s4[w]; ch = true; }
+            for (int w = 0; w < NW; ++w)
+                if (s4[w] != reach[r * NW + w]) { reach[r * NW + w] = s4[w]; ch = true; }
         }
         if (ch) *changed = 1;
         sync();
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
             }
         }
         __syncthreads();
-        const bool converged = relax_row_bitmaps(pass, reach, H, H * W, threadIdx.x, 256u, &changed, [] { __syncthreads(); });
+        const bool converged = relax_row_bitmaps<4>(pass, reach, H, H * W, threadIdx.x, 256u, &changed, [] { __syncthreads(); });
         // back to the tick's interleaved layout, in place: component j of row r = every fourth bit from bit j
         __syncthreads();
         for (uint32_t r = threadIdx.x; r < H; r += 256u) {
@@ -937,16 +938,17 @@ __device__ __forceinline__ void env_sync()
 
 // STAGE: the environment's grid (and its reachability bytes) fit the slot's LDS: they are staged there by batched,
 // independent loads - one memory latency per environment instead of one per pass - and flood and tick read LDS.
-// BM: the flood runs on linear row bitmaps (wf_tiled_prologue's run fill) - instantiated for the workgroup-per-environment
-// grids only: its 256-bit row arithmetic costs the wave-per-environment kernel half its occupancy.
+// BM: words per row of the linear row bitmaps the flood runs on (wf_tiled_prologue's run fill): 4 for the
+// workgroup-per-environment grids (W <= 256), 1 for the wave-per-environment ones (W <= 64; the 256-bit row arithmetic
+// would cost that kernel half its occupancy); wider grids flood on the byte board (bm_off == 0).
 #ifndef WF_ENV_WAVES
 #define WF_ENV_WAVES 6          // waves per SIMD of the wave-per-environment instantiations (4 / 6 / 8: 101 / 91 / 93 us per 65 536 x 14x14 wind step)
 #endif
-template <int NT, bool WIND, bool STAGE, bool BM>
+template <int NT, bool WIND, bool STAGE, int BM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? WF_ENV_WAVES : 4, 8))) void wf_step_env(const WfArgs a, const uint8_t *mode, uint32_t slot_bytes, uint32_t bm_off)
 {
     // per environment slot: [STAGE: the grid, one word per cell] [reachability byte board | river row table]
-    // [bm_off != 0: two linear row bitmaps of 256 bits per row for the flood (W <= 256)]
+    // [bm_off != 0: two linear row bitmaps of BM words per row for the flood]
     extern __shared__ __attribute__((aligned(16))) uint8_t env_lds[];
     constexpr uint32_t EPB = 256 / NT;
     __shared__ uint32_t red[EPB][4];                 // flags, healthy, changed (flood), -
@@ -967,16 +969,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
         if constexpr (STAGE) {
             const bool want_reach = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
             env_sync<NT>();                           // the slot's last environment is done with it
-            for (uint32_t q0 = 0; q0 < cells; q0 += NT * 8u) {
-                uint32_t v[8], r[8];
+            constexpr int U = 4;                      // loads in flight per lane and trip (x2 with the reachability bytes)
+            for (uint32_t q0 = 0; q0 < cells; q0 += NT * (uint32_t)U) {
+                uint32_t v[U], r[U];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < U; ++k) {
                     const uint32_t q = q0 + (uint32_t)k * NT + t;
                     v[k] = q < cells ? se[q] : 0u;
                     r[k] = (want_reach && q < cells) ? (uint32_t)reach_e[q] : 0u;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < U; ++k) {
                     const uint32_t q = q0 + (uint32_t)k * NT + t;
                     if (q < cells) { ls[q] = v[k]; if (want_reach) board[q] = (uint8_t)(r[k] << 2); }
                 }
@@ -1015,12 +1018,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
         const bool upd = (a.update_mask & 1ull) != 0, precheck = (m & MODE_PRECHECK) != 0, flood = (m & MODE_FLOOD) != 0;
         auto src = [&](uint32_t q) -> uint32_t { if constexpr (STAGE) return ls[q]; else return se[q]; };
         uint32_t valid = 0;
-        if (BM && flood && bm_off) {
+        if (flood && bm_off) {
             // border-reachability board through linear row bitmaps (as wf_tiled_prologue): passable cells and seeds per
             // row, then one thread per row takes what the rows above and below reached and fills along the row's runs
-            u64 *pass = reinterpret_cast<u64 *>(env_lds + (size_t)slot * slot_bytes + bm_off), *reach = pass + H * 4u;
-            for (uint32_t k = t; k < H * 4u; k += NT) {
-                const uint32_t r = k >> 2, w = k & 3u, x0 = w * 64u;
+            u64 *pass = reinterpret_cast<u64 *>(env_lds + (size_t)slot * slot_bytes + bm_off), *reach = pass + H * (uint32_t)BM;
+            for (uint32_t k = t; k < H * (uint32_t)BM; k += NT) {
+                const uint32_t r = k / (uint32_t)BM, w = k % (uint32_t)BM, x0 = w * 64u;
                 u64 mk = 0;
                 if (x0 < W) {
                     const uint32_t n = min(64u, W - x0);
@@ -1033,8 +1036,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
                 reach[k] = mk & seeds;
             }
             env_sync<NT>();
-            relax_row_bitmaps(pass, reach, H, cells, t, (uint32_t)NT, &red[slot][2], [] { env_sync<NT>(); });
-            auto reached = [&](uint32_t x, uint32_t y) -> uint32_t { return (uint32_t)(reach[y * 4u + (x >> 6)] >> (x & 63u)) & 1u; };
+            relax_row_bitmaps<BM>(pass, reach, H, cells, t, (uint32_t)NT, &red[slot][2], [] { env_sync<NT>(); });
+            auto reached = [&](uint32_t x, uint32_t y) -> uint32_t { return (uint32_t)(reach[y * (uint32_t)BM + (x >> 6)] >> (x & 63u)) & 1u; };
             for (uint32_t q = t; q < cells; q += NT) {
                 const uint32_t y = q / W, x = q - y * W;
                 uint32_t v = reached(x, y);
@@ -1087,18 +1090,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
             valid = WF_F_REACH_VALID;
         }
         // ---- the tick, with the environment's reductions in wave-uniform registers
-        const uint32_t code = WIND ? (uint32_t)a.envs[e].wind : 0u;
-        const double *wc = WIND ? cold->wind_c[(code >> 4) & 3u][code & 15u] : nullptr;
-        const double threshold = WIND ? cold->p.threshold : 0.0;
+        double wc[4] = { 0.0, 0.0, 0.0, 0.0 }, threshold = 0.0;      // wind: this environment's addends per direction
+        if (WIND) {
+            const uint32_t code = ev.y >> 16;
+            const double *tab = cold->wind_c[(code >> 4) & 3u][code & 15u];
+            wc[0] = tab[0]; wc[1] = tab[1]; wc[2] = tab[2]; wc[3] = tab[3];
+            threshold = cold->p.threshold;
+        }
         uint32_t A = 0, healthy = 0;
+        // (x, y) of this lane's cell, advanced from pass to pass without a division
+        uint32_t y = t / W, x = t - y * W;
+        const uint32_t step_y = (uint32_t)NT / W, step_x = (uint32_t)NT - step_y * W;
         // every lane takes its cell, the four neighbours and the reachability byte up front (clamped addresses, the
         // words masked where the grid ends): nothing in a pass depends on the last one
         for (uint32_t q0 = 0; q0 < cells; q0 += NT) {
             const uint32_t q = q0 + t;
             const bool in = q < cells;
             const uint32_t qc = in ? q : cells - 1u;
-            const uint32_t y = qc / W, x = qc - y * W;
-            const bool top = y == 0, bottom = y == H - 1, left = x == 0, right = x == W - 1;
+            const uint32_t yc = in ? y : H - 1u, xc = in ? x : W - 1u;
+            const bool top = yc == 0, bottom = yc == H - 1, left = xc == 0, right = xc == W - 1;
+            x += step_x;
+            y += step_y;
+            if (x >= W) { x -= W; ++y; }
             uint32_t c = src(qc);
             const uint32_t vS = src(top ? qc : qc - W), vN = src(bottom ? qc : qc + W);
             const uint32_t vE = src(left ? qc : qc - 1u), vW = src(right ? qc : qc + 1u);
@@ -1261,9 +1274,8 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         if ((a.hot_flags & WF_HOT_RIVERS) && aux < (size_t)a.H * 2) aux = (size_t)a.H * 2;   // river row table
         aux = (aux + 15) & ~(size_t)15;
         const bool wave = cells <= 1024;
-        // flood on two 256-bit bitmaps per row - for the workgroup-per-environment grids: up to 1 024 cells the
-        // cell-at-a-time relaxation of a wave is the faster one (65 536 x 15x15: 71 against 91 us per step)
-        size_t bm = (cont && a.W <= 256 && !wave) ? (size_t)a.H * 64 : 0;
+        // flood on two row bitmaps: 256 bits per row for the workgroup-per-environment grids, 64 for a wave's
+        size_t bm = !cont ? 0 : (!wave && a.W <= 256) ? (size_t)a.H * 64 : (wave && a.W <= 64) ? (size_t)a.H * 16 : 0;
         const unsigned epb = wave ? 4u : 1u;
         const size_t words = (cells * 4 + 15) & ~(size_t)15;                     // the staged grid (16-byte granules, like every part)
         const bool stage = (words + aux + bm) * epb <= 20480;
@@ -1273,7 +1285,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         unsigned blocks = (unsigned)((a.batch + epb - 1) / epb);
         if (blocks > 8192) blocks = 8192;
 #define WF_ENV_LAUNCH(NT, WIND, STAGE) \
-        hipLaunchKernelGGL((wf_step_env<NT, WIND, STAGE, NT == 256>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot, bm_off)
+        hipLaunchKernelGGL((wf_step_env<NT, WIND, STAGE, (NT == 256 ? 4 : 1)>), dim3(blocks), dim3(256), slot * epb, s, a, (const uint8_t *)mode, (uint32_t)slot, bm_off)
         if (wave) {
             if (wind) { if (stage) WF_ENV_LAUNCH(64, true, true); else WF_ENV_LAUNCH(64, true, false); }
             else { if (stage) WF_ENV_LAUNCH(64, false, true); else WF_ENV_LAUNCH(64, false, false); }
