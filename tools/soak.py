@@ -1,5 +1,5 @@
 """Long randomized differential run of the HIP step against the CPU oracle (not part of pytest).
-usage (GPU box): [WF_GROUP=8] [STEPS_PER_CALL=k] python tools/soak.py [steps] [batch] [size] [seed]
+usage (GPU box): [WF_GROUP=8] [STEPS_PER_CALL=k] [OPTIONS=wind,rivers,toggle] python tools/soak.py [steps] [batch] [size] [seed]
 Every step: rewards and done flags; every 25 steps: full planes, records and the observation."""
 import os
 import sys
@@ -15,11 +15,23 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 VIS = np.uint16(~np.uint16(128 | 256))
 
-env = BatchedForestFire(B, size=S, seed=seed, auto_reset=True, containment=True, fuel_range=(3, 25), ignite_ppm=3000)
+OPTS = set(filter(None, os.environ.get("OPTIONS", "").split(",")))      # the reference's off-by-default options
+md, okw = {}, {}
+if "wind" in OPTS:
+    md["wind"] = "random"
+    okw.update(wind_mode=2, wind_speeds=[0.0, 0.7, 0.85, 0.0])
+if "rivers" in OPTS:
+    md["make_rivers"] = True
+    okw.update(make_rivers=1)
+if "toggle" in OPTS:
+    md.update(allow_dig_toggle=True, n_actions=5)
+    okw.update(allow_dig_toggle=1)
+env = BatchedForestFire(B, size=S, seed=seed, auto_reset=True, containment=True, fuel_range=(3, 25), ignite_ppm=3000, metadata=md or None)
 env.reset(seed=seed)
-op = O.default_params(containment=1, fuel_lo=3, fuel_hi=25, ignite_ppm=3000)
+op = O.default_params(containment=1, fuel_lo=3, fuel_hi=25, ignite_ppm=3000, **okw)
 planes, envs = O.new_state(B, S, S)
-O.reset(planes, envs, seed=seed, params=op)
+counts = np.zeros(planes.shape, np.uint8) if "wind" in OPTS else None
+O.reset(planes, envs, seed=seed, params=op, counts=counts)
 rng = np.random.default_rng(seed)
 t0 = time.time()
 paid = resets = deaths = 0
@@ -43,9 +55,9 @@ for t in range(T):
     else:
         obs, r, d, _ = env.step(a)
     stopped = (envs["flags"] & O.F_RUNNING) == 0
-    ro, do = O.step(planes, envs, a, op)
+    ro, do = O.step(planes, envs, a, op, counts=counts)
     if stopped.any():
-        O.reset(planes, envs, seed=seed, mask=stopped, params=op)
+        O.reset(planes, envs, seed=seed, mask=stopped, params=op, counts=counts)
         ro[stopped], do[stopped] = 0.0, 0
         resets += int(stopped.sum())
     assert np.array_equal(r, ro), f"reward t={t}: {np.flatnonzero(r != ro)[:8]}"
@@ -58,6 +70,8 @@ for t in range(T):
         ge["flags"] &= VIS
         assert np.array_equal(gp, planes), f"planes t={t}: envs {np.unique(np.nonzero(gp != planes)[0])[:8]}"
         assert np.array_equal(ge, envs), f"records t={t}"
+        if counts is not None:
+            assert np.array_equal(env.download_counts(), counts), f"wind counts t={t}"
         assert np.array_equal(env.get_state() if obs is None else obs, O.get_state(planes)), f"obs t={t}"
     if t % 250 == 0:
         print(f"t={t} ok  resets={resets} contained={paid} deaths={deaths}  {time.time() - t0:.0f}s", flush=True)
