@@ -17,7 +17,7 @@ RUNS = [  # (directory, what was run)
     ("kt_c3_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline   (65 536 x 14x14, ONE launch per step: compare "
                      "AverageNs with roofline.single_launch.launch_us of the bench line)"),
     ("kt_c4", "python3 bench.py --no-extras --no-cpu-baseline --size 256 --batch 1024 --noop --ignite-ppm 10000 --steps 200 --warmup 20"
-              "   (BASELINE configs[3]; a step = 2 concurrent launch sequences on 2 streams)"),
+              "   (BASELINE configs[3]; a step = 3 concurrent launch sequences on 3 streams, each over a third of the batch)"),
     ("kt_c4_single", "WF_NO_SPLIT=1, same command   (BASELINE configs[3], one launch sequence per step: the per-kernel durations add up to the step)"),
     ("kt_hbm_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline --batch 1048576 --steps 120 --warmup 20"
                       "   (1 048 576 x 14x14 = 822 MB of state: true HBM streaming, one launch per step)"),

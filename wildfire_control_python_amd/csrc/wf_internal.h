@@ -66,7 +66,7 @@ struct WfKnobs {
     int group;       // WF_GROUP: cap on environments per wave of the single-step kernel (0 = automatic)
     int split_min;   // WF_SPLIT_MIN: smallest batch stepped as concurrent part launches (0 = automatic)
     int no_split;    // WF_NO_SPLIT: one launch per step
-    int n_parts;     // WF_SPLIT: launches per step of a large batch (default 2)
+    int n_parts;     // WF_SPLIT: launches per step of a large batch (0: automatic; wf_create stores the number it settled on)
     int shared;      // WF_SHARED=N: workgroup-shared agent phases (N waves per workgroup; 1 = automatic)
     int rows;        // WF_ROWS: keep the rows layout for group overrides beyond 16
     int no_rows;     // WF_NO_ROWS: 4-cells-per-lane group layout only

@@ -442,7 +442,7 @@ void wf_read_knobs(WfKnobs *k)
     k->group = num("WF_GROUP", 0);
     k->split_min = num("WF_SPLIT_MIN", 0);
     k->no_split = set("WF_NO_SPLIT");
-    k->n_parts = num("WF_SPLIT", 2);
+    k->n_parts = num("WF_SPLIT", 0);      // 0: automatic (wf_create: 2 for the wave family, 3 for the big-grid families)
     k->shared = set("WF_SHARED") ? (num("WF_SHARED", 1) > 1 ? num("WF_SHARED", 1) : 1) : 0;
     k->rows = set("WF_ROWS");
     k->no_rows = set("WF_NO_ROWS");
