@@ -176,8 +176,8 @@ int wf_reset_device(wf_ctx *ctx, const uint8_t *d_mask, uint64_t seed);
  * Ordering of the *_device calls: with a caller stream (wf_set_stream) everything is enqueued on that
  * stream, in order.  With the context's OWN streams (the default) the calls of one context are ordered
  * among themselves, the device buffers handed in must be complete when the call is made, and results
- * are complete after wf_sync / wf_timer_stop (a large single step is issued as two concurrent
- * half-batch launches on two internal streams; every other call joins them first). */
+ * are complete after wf_sync / wf_timer_stop (a large single step is issued as two - big grids: three - concurrent
+ * launches over shares of the batch on internal streams; every other call joins them first). */
 int wf_step(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mask,
             double *reward, uint8_t *done);
 int wf_step_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
@@ -207,7 +207,7 @@ int wf_timer_stop(wf_ctx *ctx, float *elapsed_ms);   /* synchronises */
 
 /* Introspection: name of the kernel family serving this context's grid shape; symbol of the kernel
  * behind a single step (n_steps == 1) of this context, and how many concurrent launches of it one
- * step is (large batches on the context's own streams are stepped as two half-batch launches). */
+ * step is (large batches on the context's own streams are stepped as two or three launches over shares of the batch). */
 const char *wf_kernel_name(const wf_ctx *ctx);
 const char *wf_step_kernel_name(const wf_ctx *ctx);
 int wf_step_launches(const wf_ctx *ctx);
