@@ -679,6 +679,7 @@ __device__ __forceinline__ bool relax_row_bitmaps(const u64 *pass, u64 *reach, u
 __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t *mode, u64 *halo, uint32_t rows_per_wg)
 {
     extern __shared__ u64 lds[];                     // flood: [H*4] pass, [H*4] reach
+    __shared__ u64 pm[4][8][4];                      // flood: the interleaved passable masks of a wave's current 8 rows
     __shared__ uint32_t s_mode, changed;
     const uint32_t e = blockIdx.x;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2, words = H * 4u;
@@ -697,25 +698,45 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
     if (md & MODE_FLOOD) {                                           // (only set with the containment test on)
         u64 *pass = lds, *reach = lds + words;
-        // passable masks, one row per wave iteration; kept LINEAR for the flood: bit x % 64 of word [r][x / 64]
-        // (the ballots give the interleaved layout of the tick - bit l of component j = cell x = 4l + j)
-        for (uint32_t r = wv; r < H; r += 4u) {
-            uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
-            if (lane < LW) c = src[r * LW];
-            const u64 P[4] = { __ballot((c.x & 0xffu) < WF_DIRT), __ballot((c.y & 0xffu) < WF_DIRT),
-                               __ballot((c.z & 0xffu) < WF_DIRT), __ballot((c.w & 0xffu) < WF_DIRT) };
-            if (lane < 4u) {
-                const uint32_t w = lane;                             // linear word w holds the quads 16w .. 16w+15
-                const u64 lin = spread4(P[0] >> (16u * w)) | (spread4(P[1] >> (16u * w)) << 1) |
-                                (spread4(P[2] >> (16u * w)) << 2) | (spread4(P[3] >> (16u * w)) << 3);
-                pass[r * 4 + w] = lin;
-                // seeds: passable border cells (first / last row; x == 0; x == W-1)
-                const bool edge = r == 0 || r == H - 1;
-                u64 bm = edge ? ~0ull : 0ull;
-                if (w == 0) bm |= 1ull;
-                if (w == (W - 1u) >> 6) bm |= 1ull << ((W - 1u) & 63u);
-                reach[r * 4 + w] = lin & bm;
+        // passable masks; kept LINEAR for the flood: bit x % 64 of word [r][x / 64] (the ballots give the interleaved
+        // layout of the tick - bit l of component j = cell x = 4l + j).  A wave takes 8 consecutive rows per trip and
+        // requests them all before it looks at the first: a row per trip made the build one memory latency per row,
+        // 32 to 64 of them in a row for a 128- or 256-row grid (40-100 us, with the whole launch waiting)
+        for (uint32_t rb = wv * 8u; rb < H; rb += 32u) {
+            uint4 cq[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t r = rb + (uint32_t)k;
+                cq[k] = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+                if (lane < LW && r < H) cq[k] = src[r * LW];
             }
+            // the four interleaved masks of each of the 8 rows go through LDS, so that lane (k, w) = (row of the trip,
+            // linear word) interleaves ONE word - the four 16 -> 64 bit spreads once per trip instead of once per row
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint4 c = cq[k];
+                const u64 P[4] = { __ballot((c.x & 0xffu) < WF_DIRT), __ballot((c.y & 0xffu) < WF_DIRT),
+                                   __ballot((c.z & 0xffu) < WF_DIRT), __ballot((c.w & 0xffu) < WF_DIRT) };
+                if (lane < 4u) pm[wv][k][lane] = lane == 0u ? P[0] : lane == 1u ? P[1] : lane == 2u ? P[2] : P[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint32_t k = lane >> 2, w = lane & 3u, r = rb + k;
+                if (lane < 32u && r < H) {
+                    const u64 lin = spread4(pm[wv][k][0] >> (16u * w)) | (spread4(pm[wv][k][1] >> (16u * w)) << 1) |
+                                    (spread4(pm[wv][k][2] >> (16u * w)) << 2) | (spread4(pm[wv][k][3] >> (16u * w)) << 3);
+                    pass[r * 4 + w] = lin;
+                    // seeds: passable border cells (first / last row; x == 0; x == W-1)
+                    const bool edge = r == 0 || r == H - 1;
+                    u64 bm = edge ? ~0ull : 0ull;
+                    if (w == 0) bm |= 1ull;
+                    if (w == (W - 1u) >> 6) bm |= 1ull << ((W - 1u) & 63u);
+                    reach[r * 4 + w] = lin & bm;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         const bool converged = relax_row_bitmaps<4>(pass, reach, H, H * W, threadIdx.x, 256u, &changed, [] { __syncthreads(); });
