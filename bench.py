@@ -414,7 +414,7 @@ def main():
             env.step_many(a_np[s])
         th = time.perf_counter() - th
         host_api = {"cell_updates_per_s": cells * 29 / th, "us_per_step": th / 29 * 1e6,
-                    "note": "wf_step(): H2D actions + launch + D2H reward/done + stream sync per step"}
+                    "note": "wf_step(): numpy in / out; the kernels read actions from and write reward/done to pinned host memory + stream sync per step"}
 
     kernel_name, step_kernel, step_launches, containment = env.kernel_name, env.step_kernel, env.step_launches, env.containment
     env.close()

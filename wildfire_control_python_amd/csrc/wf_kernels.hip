@@ -319,6 +319,12 @@ __global__ __launch_bounds__(256) void wf_get_state_kernel(const uint32_t *__res
 
 // Host uploads replace planes/scalars behind the context's back: the cached
 // border-reachability bitboards are no longer trustworthy.
+// small device -> pinned-host copies of wf_download (a kernel costs a launch; a DMA operation per array costs more)
+__global__ __launch_bounds__(256) void wf_copy_words_kernel(const uint32_t *src, uint32_t *dst, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void wf_invalidate_reach_kernel(wf_env *envs, int batch)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -532,6 +538,15 @@ hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num
 {
     if (fam == WF_FAM_WAVE) { WfKnobs k = {}; return dispatch_wave(true, a, k, s, num_cus); }
     return hipErrorInvalidValue;
+}
+
+hipError_t wf_launch_copy_words(const void *src, void *dst, size_t bytes, hipStream_t s)
+{
+    const uint32_t n = (uint32_t)(bytes / 4);
+    unsigned blocks = (n + 255u) / 256u;
+    if (blocks > 1024u) blocks = 1024u;
+    if (n) hipLaunchKernelGGL(wf_copy_words_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t *>(src), static_cast<uint32_t *>(dst), n);
+    return hipGetLastError();
 }
 
 hipError_t wf_launch_invalidate_reach(wf_env *envs, int batch, hipStream_t s)

@@ -70,6 +70,7 @@ class World:
         self._env = np.zeros((), dtype=N.ENV_DTYPE)
         self.agents = []
         self.RUNNING = False
+        self._burning_cells, self._border_points, self._contained = None, None, False
 
     # -- refreshed after every reset/step
     def _refresh(self):
@@ -87,13 +88,31 @@ class World:
             self.agents = [Agent(self, self._env["x"], self._env["y"], fl & N.F_DIGGING, fl & N.F_DEAD)]
         else:
             self.agents = []
-        ys, xs = np.nonzero((self._planes[:, :, N.P_TYPE] & 3) == 1)      # fire, or dirt dug under a fire (code 5)
-        self.burning_cells = set(zip(xs.tolist(), ys.tolist()))
-        # the reference's deque shrinks while it searches; only "empty <=> containment
-        # already paid" is observable to callers (environment.py:345, misc.py:39)
-        self.border_points = deque()
-        if not (fl & N.F_CONTAINED):
-            self.reset_border_points()
+        self._burning_cells = None               # built on first use (the learners' hot loop reads neither)
+        self._contained = bool(fl & N.F_CONTAINED)
+        self._border_points = None
+
+    @property
+    def burning_cells(self):
+        """World.burning_cells (environment.py:202): the set of (x, y) of every cell that burns."""
+        if self._burning_cells is None:
+            ys, xs = np.nonzero((self._planes[:, :, N.P_TYPE] & 3) == 1)      # fire, or dirt dug under a fire (code 5)
+            self._burning_cells = set(zip(xs.tolist(), ys.tolist()))
+        return self._burning_cells
+
+    @property
+    def border_points(self):
+        """The reference's deque shrinks while it searches; only "empty <=> containment already paid" is observable
+        to callers (environment.py:345, misc.py:39)."""
+        if self._border_points is None:
+            self._border_points = deque()
+            if not self._contained:
+                self.reset_border_points()
+        return self._border_points
+
+    @border_points.setter
+    def border_points(self, value):
+        self._border_points = value
 
     def reset_border_points(self):
         """All border coordinates ([x, y] pairs, corners twice like the reference's deque, environment.py:215-222).
