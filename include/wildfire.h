@@ -25,7 +25,7 @@
  *           indexes env[x, y, layer], environment.py:38-50; the transpose happens
  *           only in wf_get_state).  One 32-bit word per cell:
  *             plane 0 type   0 grass 1 fire 2 burnt 3 dirt 4 water (utility.py:128-140);
-                            5 / 6 only with allow_dig_toggle, see WF_DIRT_BURNING below
+ *                          5 / 6 only with allow_dig_toggle, 13 only with make_rivers: see WF_DIRT_BURNING below
  *             plane 1 fuel   (utility.py:99; reduce_fuel environment.py:297-307)
  *             plane 2 heat   number of heat quanta received = temp / (wind_speed*heat)
  *                            (environment.py:286-290); WF_HEAT_FORCED marks
@@ -61,7 +61,14 @@ enum { WF_GRASS = 0, WF_FIRE = 1, WF_BURNT = 2, WF_DIRT = 3, WF_WATER = 4,
         * contexts without it run kernels that know neither code (do not upload them there, and do not switch the
         * option off with wf_set_params while such cells exist). */
        WF_DIRT_BURNING = 5,     /* reference: type dirt, member of burning_cells, fire_mobility inf */
-       WF_BURNT_BLOCKED = 6 };  /* reference: type burnt, fire_mobility inf (dig() turns it into WF_DIRT) */
+       WF_BURNT_BLOCKED = 6,    /* reference: type burnt, fire_mobility inf (dig() turns it into WF_DIRT) */
+       /* One state only make_rivers can produce: reset_map may draw its river THROUGH the fire cell
+        * (environment.py:69-95; 8-16 % of the resets do) - that cell is then type water with fire_mobility inf, and
+        * set_fire_to() (:233-246) retypes it to fire.  It burns and shows as fire (is_burning() true: an agent that
+        * steps on it dies; observation plane 1 = 1), blocks the containment search like dirt (plane 2 = 0; the search
+        * still starts FROM it), and burnt out it is WF_BURNT_BLOCKED.  Accepted by contexts created with make_rivers;
+        * "burning" there is (type & 3) == 1. */
+       WF_FIRE_BLOCKED = 13 };  /* reference: type fire, member of burning_cells, fire_mobility inf */
 #define WF_HEAT_FORCED 25
 #define WF_HEAT_IGNITED 24   /* wind_mode != 0 only: plane 2 of a cell that accumulated heat ignited */
 
@@ -107,7 +114,8 @@ typedef struct wf_params {
     int32_t  fuel_lo, fuel_hi; /* fuel ~ U{lo..hi} per cell                            */
     uint32_t ignite_ppm;       /* extra pre-ignited grass cells per million             */
     int32_t  make_rivers;      /* constants.py:44: reset draws the river of reset_map (environment.py:69-95) from the
-                                * counter-based stream (same law; a river through the fire cell is redrawn)  */
+                                * counter-based stream (same law, rivers through the fire cell included:
+                                * WF_FIRE_BLOCKED)  */
     uint64_t seed;             /* stream seed for auto_reset                            */
     uint64_t env_id0;          /* global id of env 0 of this context (multi-GPU shards) */
     /* Wind with a direction (fixed at wf_create: WF_WIND_CALM cannot be switched to or from later).  The heat addend
@@ -147,8 +155,9 @@ int wf_set_params(wf_ctx *ctx, const wf_params *p);
 int wf_set_stream(wf_ctx *ctx, void *hip_stream);
 
 /* Host <-> device state exchange (synchronous).  Either pointer may be NULL to skip it.  A record whose agent position
- * lies outside the grid, or a cell type outside 0..4 (0..6 with allow_dig_toggle), is refused (WF_ERR_ARG, nothing
- * uploaded).
+ * lies outside the grid, or a cell type outside 0..4 (allow_dig_toggle: also 5, 6; make_rivers: also 6, 13), is refused
+ * (WF_ERR_ARG, nothing uploaded).  With wind, planes and heat counts form ONE state: uploading planes zeroes the counts
+ * (a new grid has received no heat); upload the counts AFTER the planes when restoring a snapshot.
  * replaces: direct numpy access to World.env (environment.py:38-50) */
 int wf_upload(wf_ctx *ctx, const int8_t *planes, const wf_env *envs);
 int wf_download(wf_ctx *ctx, int8_t *planes, wf_env *envs);

@@ -83,13 +83,12 @@ static uint32_t below(uint32_t r, uint32_t n)
 
 /* ------------------------------------------------------------------ river */
 
-/* reset_map's river (environment.py:69-95), one attempt: returns 1 if the river stays off the fire cell.
- * Draws come from the river domain of the env's stream: index 0x80000000 + attempt * 0x10000 + n. */
-static int river_attempt(int H, int W, uint64_t seed, uint64_t id, uint32_t ep, uint32_t attempt, int keep_centre,
-                         uint8_t *water)
+/* reset_map's river (environment.py:69-95).  Draws come from the river domain of the env's stream: index
+ * 0x80000000 + n.  The walk may pass through the fire cell (the acceptance test :91-92 even favours it). */
+int wfo_river(int H, int W, uint64_t seed, uint64_t id, uint32_t ep, uint8_t *water)
 {
-    uint32_t n = 0x80000000u + attempt * 0x10000u;
-    int fx = W / 2, fy = H / 2, crossed = 0;              /* utility.py:61-64 */
+    uint32_t n = 0x80000000u;
+    int fx = W / 2, fy = H / 2, cells = 0;                   /* utility.py:61-64 */
     int x, y;
 #define D() wfo_rng_u32(seed, id, ep, n++)
     memset(water, 0, (size_t)H * (size_t)W);
@@ -97,12 +96,8 @@ static int river_attempt(int H, int W, uint64_t seed, uint64_t id, uint32_t ep, 
     y = 1 + (int)below(D(), 3);                              /* :77 np.random.choice(d) */
     while (y < H - (1 + (int)below(D(), 3))) {               /* :79 */
         int nx = x, ny = y + 1, tries = 0, ok = 0;
-        if (x == fx && y == fy) {
-            crossed = 1;
-            if (!keep_centre) water[y * W + x] = 1;
-        } else {
-            water[y * W + x] = 1;                            /* :81-87 */
-        }
+        water[y * W + x] = 1;                                /* :81-87 */
+        cells++;
         do {                                                 /* :89-93 */
             int s = (D() & 1u) ? 1 : -1;                     /* np.random.choice([1, -1]) */
             int a = 1 + (int)below(D(), 3), b = 1 + (int)below(D(), 3);
@@ -115,19 +110,7 @@ static int river_attempt(int H, int W, uint64_t seed, uint64_t id, uint32_t ep, 
         y = ny;
     }
 #undef D
-    return !crossed;
-}
-
-int wfo_river(int H, int W, uint64_t seed, uint64_t env_id, uint32_t episode, uint8_t *water)
-{
-    uint32_t attempt;
-    int i, n = 0;
-    for (attempt = 0; attempt < 8; ++attempt)
-        if (river_attempt(H, W, seed, env_id, episode, attempt, attempt == 7, water))
-            break;
-    for (i = 0; i < H * W; ++i)
-        n += water[i];
-    return n;
+    return cells;
 }
 
 /* ---------------------------------------------------------- circle_points */
@@ -476,13 +459,13 @@ static void decode(world *w, const int8_t *pl, const wfo_env *e, uint8_t *counts
         int t = pl[4 * i + WFO_P_TYPE];
         /* boundary codes 5 / 6 (see wf_oracle.h): reference type dirt + member of burning_cells / reference
          * type burnt + fire_mobility inf */
-        w->type[i] = t == WFO_DIRT_BURNING ? WFO_DIRT : t == WFO_BURNT_BLOCKED ? WFO_BURNT : t;
+        w->type[i] = t == WFO_DIRT_BURNING ? WFO_DIRT : t == WFO_BURNT_BLOCKED ? WFO_BURNT : t == WFO_FIRE_BLOCKED ? WFO_FIRE : t;
         w->fmob_inf[i] = t >= WFO_DIRT;
         w->fuel[i] = pl[4 * i + WFO_P_FUEL];
         w->temp[i] = w->cnt ? temp_from_wind_counts(w, pl[4 * i + WFO_P_HEAT], w->cnt + 4 * i)
                             : temp_from_count(w, pl[4 * i + WFO_P_HEAT]);
         w->agent_pos[i] = pl[4 * i + WFO_P_AGENT];
-        if (t == WFO_FIRE || t == WFO_DIRT_BURNING)
+        if (t == WFO_FIRE || t == WFO_DIRT_BURNING || t == WFO_FIRE_BLOCKED)
             w->burning[w->n_burning++] = i;
     }
     w->ax = e->x;
@@ -507,6 +490,7 @@ static void encode(const world *w, int8_t *pl, wfo_env *e)
         int t = (int)w->type[i];
         if (t == WFO_DIRT && w->in_burning[i]) t = WFO_DIRT_BURNING;
         if (t == WFO_BURNT && w->fmob_inf[i]) t = WFO_BURNT_BLOCKED;
+        if (t == WFO_FIRE && w->fmob_inf[i]) t = WFO_FIRE_BLOCKED;     /* a river under the fire cell (:81-85, then :241) */
         pl[4 * i + WFO_P_TYPE] = (int8_t)t;
         pl[4 * i + WFO_P_FUEL] = (int8_t)w->fuel[i];
         if (w->cnt) {
@@ -689,8 +673,8 @@ int wfo_get_state(int batch, int H, int W, const int8_t *planes, int8_t *obs)
                 const int8_t *c = pl + 4 * (y * W + x);
                 int8_t *d = o + 3 * (x * H + y);             /* environment.py:399-402, [x][y][k] */
                 d[0] = c[WFO_P_AGENT];
-                d[1] = (int8_t)(c[WFO_P_TYPE] == WFO_FIRE);
-                d[2] = (int8_t)(c[WFO_P_TYPE] < WFO_DIRT);   /* fire_mobility != inf: not dirt / water / codes 5, 6 */
+                d[1] = (int8_t)(c[WFO_P_TYPE] == WFO_FIRE || c[WFO_P_TYPE] == WFO_FIRE_BLOCKED);
+                d[2] = (int8_t)(c[WFO_P_TYPE] < WFO_DIRT);   /* fire_mobility != inf: not dirt / water / codes 5, 6, 13 */
             }
     }
     return 0;

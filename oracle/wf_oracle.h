@@ -53,7 +53,12 @@ enum { WFO_GRASS = 0, WFO_FIRE = 1, WFO_BURNT = 2, WFO_DIRT = 3, WFO_WATER = 4,
         * under type dirt (is_burning() false: the agent on it survives, the observation shows dirt), and when its
         * fuel runs out reduce_fuel() retypes it to burnt with the mobility still inf. */
        WFO_DIRT_BURNING = 5,    /* reference: type dirt, in burning_cells, fire_mobility inf  */
-       WFO_BURNT_BLOCKED = 6 }; /* reference: type burnt, fire_mobility inf                    */
+       WFO_BURNT_BLOCKED = 6,   /* reference: type burnt, fire_mobility inf                    */
+       /* One state only make_rivers produces: the river of reset_map drawn through the fire cell leaves it type water
+        * with fire_mobility inf (environment.py:81-85), then set_fire_to() (:233-246) retypes it to fire.  It burns
+        * and shows as fire (is_burning() true: an agent stepping on it dies), yet blocks the containment search like
+        * dirt; burnt out it is WFO_BURNT_BLOCKED. */
+       WFO_FIRE_BLOCKED = 13 }; /* reference: type fire, in burning_cells, fire_mobility inf   */
 
 enum {
     WFO_F_ALIVE     = 1,   /* World.agents non-empty (environment.py:206-208)            */
@@ -128,9 +133,9 @@ int wfo_get_state(int batch, int H, int W, const int8_t *planes, int8_t *obs);
 
 /* The river of reset_map (environment.py:69-95) under the counter-based stream: water[y*W + x] = 1 on river cells.
  * Same law as the reference's generator - start column uniform, start row in {1,2,3}, one cell per row, the column
- * drifting by +-1 under the reference's acceptance test, the walk ending H - {1,2,3} rows down - conditioned on the
- * river not crossing the fire cell (the reference would hold a burning cell with infinite fire mobility there, which
- * the boundary format cannot express: such rivers are redrawn).  Returns the number of water cells. */
+ * drifting by +-1 under the reference's acceptance test, the walk ending H - {1,2,3} rows down.  A river may cross the
+ * fire cell (the reference's does in 8-16 % of its resets): that cell is marked too, and wfo_reset makes it
+ * WFO_FIRE_BLOCKED.  Returns the number of marked cells. */
 int wfo_river(int H, int W, uint64_t seed, uint64_t env_id, uint32_t episode, uint8_t *water);
 
 /* The counter-based stream itself (for tests of the generator). */

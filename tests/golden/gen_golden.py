@@ -46,6 +46,12 @@ ASTAR_SO = os.path.join(REPO, "oracle", "_ref", "astar.so")
 P_TYPE, P_FUEL, P_HEAT, P_AGENT = 0, 1, 2, 3
 HEAT_FORCED = 25  # round((threshold+1)/0.162): set_fire_to() on a cold cell, environment.py:236-237
 HEAT_IGNITED = 24  # wind fixtures: plane 2 only says how a cell was ignited (0 never / forced / by accumulated heat)
+FIRE_BLOCKED = 13  # type fire with fire_mobility inf: a river drawn through the fire cell (environment.py:69-95, then :233-246)
+
+# every astar_path call of the current step: (start x, start y, goal x, goal y, found).  The distinct start cells, in
+# call order, are the burning cells get_reward popped from its set copy (environment.py:349-371) - the one piece of
+# CPython-internal state (set iteration order) its result depends on when the fire is split.
+ASTAR_LOG = []
 
 
 def _install_stand_ins():
@@ -79,6 +85,7 @@ def _install_stand_ins():
         paths = np.full(h * w, -1, dtype=np.int32)
         ok = lib.astar(np.ascontiguousarray(weights, dtype=np.float32).ravel(),
                        h, w, s, g, bool(allow_diagonal), paths)
+        ASTAR_LOG.append((int(start[0]), int(start[1]), int(goal[0]), int(goal[1]), bool(ok and s != g)))
         if not ok or s == g:
             return np.array([])
         out, p = [], g
@@ -105,8 +112,9 @@ class Recorder:
         self.winds, self.temps = [], []
         self.c = 0.54 * 0.3 * (0 + 1) ** (-1)  # environment.py:286-287 with wind (0,0)
         self.rows = {k: [] for k in ("planes", "agent", "reward", "done", "obs",
-                                     "fab", "border_len", "action")}
+                                     "fab", "border_len", "action", "updated")}
         self.init_planes, self.init_agent, self.init_world, self.ep_start, self.seeds = [], [], [], [], []
+        self.pop_cells, self.pop_start = [], [0]     # burning cells popped by get_reward, per step (ragged)
 
     def _seqsum(self, n):
         t = 0.0
@@ -137,13 +145,19 @@ class Recorder:
         # Two states only allow_dig_toggle can produce (toggle_digging -> dig() on a burning cell,
         # environment.py:123-138): type dirt but still a member of burning_cells -> boundary code 5; and, once
         # its fuel is gone (reduce_fuel :297-307), type burnt with fire_mobility still inf -> code 6.
+        # A third one only make_rivers can produce: the river drawn through the fire cell (reset_map :69-95) leaves it
+        # type water with fire_mobility inf, then set_fire_to (:233-246) retypes it to fire: a burning cell that shows as
+        # fire but blocks the search -> code 13; burnt out it is type burnt, still blocked -> code 6 again.
         for (x, y) in W.burning_cells:
             if code[x, y] == 3:
                 code[x, y] = 5
             else:
                 assert code[x, y] == 1, (x, y, code[x, y])
+                if np.isinf(fm[x, y]):
+                    code[x, y] = FIRE_BLOCKED
         code[(code == 2) & np.isinf(fm)] = 6
-        assert set(zip(*np.nonzero((code == 1) | (code == 5)))) == {(int(x), int(y)) for x, y in W.burning_cells}
+        assert set(zip(*np.nonzero((code == 1) | (code == 5) | (code == FIRE_BLOCKED)))) == \
+            {(int(x), int(y)) for x, y in W.burning_cells}
         # fire_mobility is a pure function of the boundary code (environment.py:85,133)
         assert np.array_equal(np.isinf(fm), code >= 3)
         p[:, :, P_TYPE] = code.T
@@ -170,8 +184,17 @@ class Recorder:
             self.winds.append([float(W.wind_speed), float(W.wind_vector[0]), float(W.wind_vector[1])])
 
     def step(self, action):
+        del ASTAR_LOG[:]
+        tick_before = self.sim.METADATA["a_speed_iter"]
         state, reward, done, _ = self.sim.step(action)
         r = self.rows
+        r["updated"].append(tick_before == 1)                # forest_fire.py:40-43: update() ran in this step
+        last = None
+        for (sx, sy, _gx, _gy, _found) in ASTAR_LOG:
+            if (sx, sy) != last:
+                self.pop_cells.append((sx, sy))
+                last = (sx, sy)
+        self.pop_start.append(len(self.pop_cells))
         r["planes"].append(self._planes())
         r["agent"].append(self._agent())
         r["reward"].append(float(reward))
@@ -187,8 +210,10 @@ class Recorder:
     def save(self, path):
         r = self.rows
         extra = {}
+        if getattr(self, "a_speed_iter0", None) is not None:      # METADATA['a_speed_iter'] at the start of every episode
+            extra["a_speed_iter0"] = np.asarray(self.a_speed_iter0, dtype=np.int32)
         if self.wind:
-            extra = dict(wind=np.asarray(self.winds, dtype=np.float64),       # per episode: speed, wx, wy
+            extra.update(wind=np.asarray(self.winds, dtype=np.float64),       # per episode: speed, wx, wy
                          temp=np.asarray(self.temps, dtype=np.float32))      # per step: World.env[:, :, temp] as [y, x]
         np.savez_compressed(
             path,
@@ -207,6 +232,9 @@ class Recorder:
             obs=np.asarray(r["obs"], dtype=np.int8),
             fire_at_border=np.asarray(r["fab"], dtype=np.uint8),
             border_len=np.asarray(r["border_len"], dtype=np.int32),
+            updated=np.asarray(r["updated"], dtype=np.uint8),         # update() ran in this step (a_speed, forest_fire.py:40-43)
+            pop_cells=np.asarray(self.pop_cells, dtype=np.int16).reshape(-1, 2),   # (x, y) get_reward searched from ...
+            pop_start=np.asarray(self.pop_start, dtype=np.int64),     # ... step i: pop_cells[pop_start[i]:pop_start[i+1]]
         )
         print(f"  wrote {os.path.relpath(path, REPO)}: {len(self.ep_start)} episodes, "
               f"{len(r['action'])} steps, {os.path.getsize(path)} bytes")
@@ -322,24 +350,34 @@ def run_size(size):
             _, _, done = rec.step(a)
     rec.save(out("multifire"))
 
-    # 6. rivers (reset_map environment.py:69-95): water is neither burnable nor traversable
+    # 6. rivers (reset_map environment.py:69-95): water is neither burnable nor traversable.  A river may run through
+    #    the fire cell (8-16 % of them do): set_fire_to then retypes that water cell to fire and its fire_mobility stays
+    #    inf - boundary code 13 (see Recorder._planes); those seeds are part of the set.
     rec = Recorder(sim, layer, size)
     rng = np.random.default_rng(5000 + size)
     constants.METADATA["make_rivers"] = True
-    ep, seed = 0, 500
-    while ep < 10:
-        reset(seed)
+    fx, fy = size // 2, size // 2
+    crossing, seed = 0, 500
+    for ep in range(16):
+        if ep >= 12:                    # the last four episodes: the next seeds whose river crosses the fire cell
+            while True:
+                reset(seed)
+                if sim.W.env[fx, fy, layer["fire_mobility"]] == np.inf:
+                    break
+                seed += 1
+        else:
+            reset(seed)
+        crossing += int(sim.W.env[fx, fy, layer["fire_mobility"]] == np.inf)
+        rec.begin(seed)
         seed += 1
-        fx, fy = size // 2, size // 2
-        if sim.W.env[fx, fy, layer["fire_mobility"]] == np.inf:
-            continue        # river drawn through the fire cell: fire type with infinite mobility, not representable
-        rec.begin(seed - 1)
         done = False
         while not done:
             a = int(rng.integers(0, 4)) if ep % 2 == 0 else circling_policy(sim, rng)
             _, _, done = rec.step(a)
-        ep += 1
     constants.METADATA["make_rivers"] = False
+    assert crossing >= 4, crossing
+    seen = np.asarray(rec.rows["planes"])[..., P_TYPE]
+    assert (seen == FIRE_BLOCKED).any() and (seen == 6).any(), "river fixtures must hold a blocked fire cell and its burnt-out state"
     rec.save(out("river"))
 
     # 7. allow_dig_toggle (forest_fire.py:35-36): action 4 toggles dig mode.  Odd episodes are scripted so that the
@@ -411,6 +449,127 @@ def run_size(size):
     seen = {tuple(w) for w in rec.winds}
     assert len({w[0] for w in seen}) == 3 and len({w[1:] for w in seen}) >= 8, seen
     rec.save(out("wind"))
+
+    # 9. split fire (get_reward's containment search, environment.py:345-377, when the burning cells do not all lie in
+    #    one region of passable cells): scripted agents that dig BURNT cells until a wall is complete, poked dirt walls,
+    #    several ignition points.  The reference pops the burning cells from a copy of its set - the order is CPython's
+    #    (recorded in pop_cells) - and searches from the first one against the border deque it has left from earlier steps.
+    import Simulation.environment as E
+    from Simulation.utility import dirt as ref_dirt, grass as ref_grass, types as ref_types
+    real_spawn = E.get_agent_location
+    c = size // 2
+
+    def spawn_at(x, y):
+        E.get_agent_location = lambda w, h: (x, y)
+
+    def poke(cells, kind):
+        for (x, y) in cells:
+            if kind == "dirt":                                   # what Agent.dig writes (environment.py:127-133)
+                sim.W.env[x, y, layer["type"]] = ref_types["dirt"]
+                sim.W.env[x, y, layer["gray"]] = ref_dirt["gray"]
+                sim.W.env[x, y, layer["fire_mobility"]] = np.inf
+            else:                                                # what reduce_fuel writes (environment.py:302-304)
+                sim.W.env[x, y, layer["type"]] = ref_types["burnt"]
+                sim.W.env[x, y, layer["gray"]] = ref_grass["gray_burnt"]
+                sim.W.env[x, y, layer["fuel"]] = 0
+
+    def run(script, until_done=True, wait_burnt=None, tail=NOOP, max_steps=400):
+        """script: actions; "wait" = no-ops until cell wait_burnt is burnt.  Then `tail` actions until done."""
+        done, n = False, 0
+        for a in script:
+            if a == "wait":
+                while not done and sim.W.env[wait_burnt[0], wait_burnt[1], layer["type"]] != ref_types["burnt"]:
+                    _, _, done = rec.step(NOOP)
+                    n += 1
+                continue
+            if done:
+                break
+            _, _, done = rec.step(a)
+            n += 1
+        while until_done and not done and n < max_steps:
+            _, _, done = rec.step(tail if not callable(tail) else tail())
+            n += 1
+
+    Nn, Ss, Ee, Ww = 0, 1, 2, 3
+    rec = Recorder(sim, layer, size)
+    # 9a. a wall along the fire's row, closed by digging the burnt-out centre: the cell north of the centre burns on in
+    #     a one-cell pocket, the rest of the fire south of the wall
+    arc = [Nn, Nn, Ww, Ww, Ss, Ss]                               # around the centre and the cell north of it
+    west, east = c - 1, size - 1 - (c + 1)
+    wall_script = arc + [Ww] * west + [Ee] * west + [Nn, Nn, Ee, Ee, Ss, Ss] + [Ee] * east + [Ww] * east + ["wait", Ww]
+    for variant in range(3):
+        spawn_at(c + 1, c)
+        reset(900 + variant)
+        if variant == 1:                                         # the pocket cell burns for a long time
+            sim.W.env[c, c - 1, layer["fuel"]] = 90
+        if variant == 2:                                         # ... and so does the fire south of the wall
+            sim.W.env[:, :, layer["fuel"]] = np.random.default_rng(9000 + size).integers(15, 61, size=(size, size)).astype(np.float64)
+        rec.begin(900 + variant)
+        run(wall_script, wait_burnt=(c, c))
+    # 9b. the same wall inside a poked dirt box with one gap; the agent leaves along the wall and closes the gap from
+    #     outside while BOTH parts of the split fire still burn -> containment is paid with the fire in two regions
+    box = [(c + dx, c + dy) for dx in range(-3, 4) for dy in range(-3, 4) if max(abs(dx), abs(dy)) == 3 and (dx, dy) != (0, 3)]
+    for variant in range(2):
+        spawn_at(c + 1, c)
+        reset(910 + variant)
+        poke(box, "dirt")
+        if variant == 1:
+            sim.W.env[c, c - 1, layer["fuel"]] = 70
+            sim.W.env[c, c + 1, layer["fuel"]] = 70
+        rec.begin(910 + variant)
+        script = [Ee, Ww] + arc + [Ww, Ee, "wait", Ee,                       # wall (c-2..c+2, c) inside the box
+                                   Ww, Ww, Ww, Ss, Ss, Ss, Ee, Ee, Ee]       # out along the wall, round the corner, into the gap
+        run(script, wait_burnt=(c, c))
+    # 9c. a poked dirt wall from border to border, one ignition on each side; random walk on the agent's side
+    rng = np.random.default_rng(9100 + size)
+    for variant in range(3):
+        spawn_at(c + 2, c)
+        reset(920 + variant)
+        poke([(c - 2, y) for y in range(size)], "dirt")
+        sim.W.set_fire_to((1 + variant % 2, c - 1 + variant))
+        sim.W.env[:, :, layer["fuel"]] = rng.integers(8, 41, size=(size, size)).astype(np.float64)
+        rec.begin(920 + variant)
+        run([], tail=(lambda: int(rng.integers(0, 4))) if variant else NOOP)
+    # 9d. the reference's answer depends on the pop order: a short-lived fire in a chamber whose only way out is border
+    #     point [1, 0] (index 2 of the deque), and a lone fire cell among burnt cells that reaches every other border
+    #     point.  Whenever the chamber's cell is searched first the deque shrinks to 3 entries; should the lone cell
+    #     then be searched first against those, it "fails" and containment is paid although it reaches the border.
+    for variant in range(4):
+        spawn_at(c + 2, c + (variant % 2))
+        reset(930 + variant)
+        ax = 1 if variant < 2 else size - 2                       # chamber on the left / on the right
+        poke([(ax - 1, 0), (ax + 1, 0), (ax - 1, 1), (ax + 1, 1), (ax, 2), (0, size - 1)], "dirt")
+        poke([(c + 1, c), (c - 1, c), (c, c + 1), (c, c - 1)], "burnt")
+        sim.W.env[c, c, layer["fuel"]] = 60
+        sim.W.set_fire_to((ax, 1))
+        sim.W.env[ax, 1, layer["fuel"]] = 6 + variant
+        rec.begin(930 + variant)
+        run([], max_steps=80)
+    E.get_agent_location = real_spawn
+    n_multi = int((np.diff(rec.pop_start) > 1).sum())
+    assert n_multi > 20, n_multi                                  # steps in which more than one burning cell was searched from
+    rec.save(out("splitfire"))
+
+    # 10. a_speed = 2 (forest_fire.py:40-43): update() runs on every second step, counted by METADATA['a_speed_iter'],
+    #     which is module-global and is NOT touched by reset() (:52-54): an episode with an odd number of steps leaves
+    #     the next one out of phase.  Several episodes back to back; the counter is only ever written by step().
+    rec = Recorder(sim, layer, size)
+    rng = np.random.default_rng(9500 + size)
+    constants.METADATA["a_speed"] = 2
+    iters = []
+    for ep in range(10):
+        reset(950 + ep)
+        iters.append(int(constants.METADATA["a_speed_iter"]))
+        rec.begin(950 + ep)
+        done = False
+        while not done:
+            a = int(rng.integers(0, 4)) if ep % 2 == 0 else circling_policy(sim, rng)
+            _, _, done = rec.step(a)
+    constants.METADATA["a_speed"] = 1
+    constants.METADATA["a_speed_iter"] = 1
+    assert len(set(iters)) == 2, iters                            # both phases occur at an episode start
+    rec.a_speed_iter0 = iters
+    rec.save(out("aspeed2"))
 
 
 def main():

@@ -12,9 +12,9 @@ The device reset draws from a counter-based stream (numpy's legacy generator is 
 it can agree with the reference in DISTRIBUTION only; tests/test_reset_law.py compares the build's samples with these
 histograms (two-sample chi-square).  Only histograms (data) are stored: tests/golden/ref_reset_stats_<size>.npz.
 
-Rivers that cross the fire cell are tallied separately (`n_crossing`) and excluded from the histograms: the
-reference then holds a burning cell with infinite fire mobility, a state the boundary format does not express, and
-the device generator redraws such rivers (oracle/wf_oracle.h: wfo_river).
+Rivers that cross the fire cell (the reference then holds a burning cell with infinite fire mobility: boundary code
+13, WF_FIRE_BLOCKED) are part of the histograms like any other; `n_crossing` counts them, so that the rate at which
+the build's generator crosses the fire cell can be compared too.
 """
 import argparse
 import os
@@ -56,7 +56,6 @@ def run_size(size):
         water = env[:, :, layer["type"]] == types["water"]      # [x, y]
         if water[fx, fy]:
             n_cross += 1
-            continue
         xs, ys = np.nonzero(water)
         order = np.argsort(ys)
         xs, ys = xs[order], ys[order]
@@ -79,7 +78,7 @@ def run_size(size):
     np.savez_compressed(out, size=np.int32(size), n_rivers=np.int64(N_RIVERS), n_crossing=np.int64(n_cross),
                         start_col=start_col, start_row=start_row, length=length, drift=drift, col_cells=col_cells,
                         spawn=spawn, spawn_points=np.asarray(pts, dtype=np.int16))
-    print(f"  wrote {os.path.basename(out)}: {N_RIVERS - n_cross} rivers (+{n_cross} through the fire cell), {N_SPAWNS} spawns")
+    print(f"  wrote {os.path.basename(out)}: {N_RIVERS} rivers ({n_cross} through the fire cell), {N_SPAWNS} spawns")
 
 
 def main():

@@ -34,23 +34,94 @@ def _envs(ge):
 # --------------------------------------------------------------- reference fixtures
 @pytest.mark.parametrize("path", fixture_files(), ids=lambda p: p.split("/")[-1])
 def test_hip_reproduces_reference(wf, path):
+    """Every fixture generated from the real reference, replayed on the device.  The split-fire fixtures carry the
+    build's rule where the reference's answer depends on CPython's set order (Episodes._sigma_star; the steps are
+    enumerated in tests/test_oracle_golden.py); everything else is the reference's record bit for bit."""
     ep = Episodes(path)
-    md = {"allow_dig_toggle": True, "n_actions": 5} if "toggle" in path else None     # constants.py:46 as the generator set it
+    md = {}
+    if "toggle" in path:
+        md = {"allow_dig_toggle": True, "n_actions": 5}                               # constants.py:46 as the generator set it
+    if "river" in path:
+        md = {"make_rivers": True}                                                    # constants.py:44 (code 13 cells)
     if ep.wind:
         md = {"wind": "random"}                                                       # constants.py:39
-    env = wf.BatchedForestFire(ep.B, size=ep.size, metadata=md)
-    env.upload(ep.init_planes, ep.init_envs, counts=np.zeros(ep.init_planes.shape, np.uint8) if ep.wind else None)
+    # a_speed fixtures: the reference's global counter starts every episode in one of two phases (it survives reset());
+    # env b = episode b, so the episodes of each phase form one context whose counter starts where theirs did
+    groups = [(np.arange(ep.B), dict(md))]
+    if ep.a_speed_iter0 is not None:
+        groups = [(np.nonzero(ep.a_speed_iter0 == it)[0], dict(md, a_speed=2, a_speed_iter=int(it)))
+                  for it in sorted(set(ep.a_speed_iter0.tolist()))]
+    envs_ = []
+    for idx, m in groups:
+        e = wf.BatchedForestFire(len(idx), size=ep.size, metadata=m or None)
+        e.upload(np.ascontiguousarray(ep.init_planes[idx]), ep.init_envs[idx],
+                 counts=np.zeros((len(idx),) + ep.init_planes.shape[1:], np.uint8) if ep.wind else None)
+        envs_.append(e)
     n_contained = 0
+    planes, envs = ep.init_planes.copy(), ep.init_envs.copy()
+    obs = np.zeros((ep.B, ep.size, ep.size, 3), np.int8)
+    reward, done = np.zeros(ep.B), np.zeros(ep.B, np.uint8)
+    counts = np.zeros(ep.init_planes.shape, np.uint8) if ep.wind else None
     for t in range(ep.T):
         actions, _ = ep.actions_at(t)
-        obs, reward, done, _ = env.step(actions)
-        planes, envs = env.download()
-        live = ep.check_step(t, planes, envs, reward, done.astype(np.uint8), obs, what="hip")
+        for (idx, _), e in zip(groups, envs_):
+            obs[idx], reward[idx], d, _ = e.step(actions[idx])
+            done[idx] = d
+            planes[idx], envs[idx] = e.download()
+            if ep.wind:
+                counts[idx] = e.download_counts()
+        live = ep.check_step(t, planes, envs, reward, done, obs, what="hip")
         if ep.wind:
-            ep.check_temp(t, planes, env.download_counts(), what="hip")
+            ep.check_temp(t, planes, counts, what="hip")
         n_contained += int((reward[live] == 1000.0).sum())
     if "circle" in path:
         assert n_contained > 0
+    if "river" in path:
+        assert (ep.d["planes"][..., 0] == 13).any()
+    for e in envs_:
+        e.close()
+
+
+@pytest.mark.parametrize("variant", ["group", "rows", "fused", "cells"])
+@pytest.mark.parametrize("size", [10, 14])
+def test_split_fire_fixtures_in_every_kernel_family(wf, monkeypatch, variant, size):
+    """The split-fire fixtures (scripted agents that dig burnt cells until a wall is complete, poked walls, several
+    ignition points; gen_golden.py section 9) through each kernel family that serves a 10x10 / 14x14 grid."""
+    for k in ("WF_NO_ROWS", "WF_GROUP", "WF_SHARED", "WF_ROWS", "WF_FAMILY"):
+        monkeypatch.delenv(k, raising=False)
+    if variant == "group":
+        monkeypatch.setenv("WF_NO_ROWS", "1")
+    if variant == "rows":
+        monkeypatch.setenv("WF_GROUP", "2")
+    if variant == "cells":
+        monkeypatch.setenv("WF_FAMILY", "cells")
+    ep = Episodes([f for f in fixture_files(size) if f.endswith("_splitfire.npz")][0])
+    env = wf.BatchedForestFire(ep.B, size=size)
+    if variant in ("group", "rows"):
+        assert env.step_kernel.startswith("wf_step_" + variant), env.step_kernel
+    if variant == "cells":
+        assert env.step_kernel == "wf_step_env"
+    env.upload(ep.init_planes, ep.init_envs)
+    t = 0
+    while t < ep.T:
+        n = min(3, ep.T - t) if variant == "fused" else 1
+        acts = np.stack([ep.actions_at(t + k)[0] for k in range(n)])
+        if variant == "fused":
+            r, d = env.step_many(acts)
+        else:
+            _, r1, d1, _ = env.step(acts[0])
+            r, d = r1[None], d1[None]
+        for k in range(n):
+            live = ep.lengths > t + k
+            np.testing.assert_array_equal(r[k][live], ep.exp_reward[ep.ep_start[:-1][live] + t + k], err_msg=f"reward t={t + k}")
+            np.testing.assert_array_equal(d[k][live], ep.expected_at(t + k, "done")[0] != 0, err_msg=f"done t={t + k}")
+        t += n
+        planes, envs = env.download()
+        live = ep.lengths > t - 1
+        np.testing.assert_array_equal(planes[live], ep.expected_at(t - 1, "planes")[0], err_msg=f"planes t={t - 1}")
+        np.testing.assert_array_equal((envs["flags"][live] & O.F_CONTAINED) != 0,
+                                      ep.exp_contained[ep.ep_start[:-1][live] + t - 1], err_msg=f"contained t={t - 1}")
+    assert len(ep.divergent) > 0
     env.close()
 
 
@@ -783,14 +854,82 @@ def test_adapter_rivers_match_reference_draw_for_draw(wf):
     for size in (10, 14):
         ep = Episodes([f for f in fixture_files(size) if f.endswith("_river.npz")][0])
         sim = wf.ForestFire(size=size, metadata={"make_rivers": True})
-        for i, seed in enumerate(ep.d["seeds"][:6]):
+        crossing = 0
+        for i, seed in enumerate(ep.d["seeds"]):
             np.random.seed(int(seed))
             random.seed(int(seed))
-            sim.reset()
+            state = sim.reset()
             planes, envs = sim._b.download()
             np.testing.assert_array_equal(planes[0], ep.init_planes[i], err_msg=f"size {size} seed {seed}")
             assert (envs["x"][0], envs["y"][0]) == tuple(ep.d["init_agent"][i, :2])
+            c = size // 2
+            if planes[0, c, c, 0] == 13:
+                # the river runs through the fire cell: it shows as fire, blocks (plane 2 = 0), and World.env reads
+                # type fire with infinite fire mobility like the reference's (environment.py:85, :241)
+                crossing += 1
+                assert state[c, c, 1] == 1 and state[c, c, 2] == 0
+                assert sim.W.env[c, c, sim.layer["type"]] == 1 and np.isinf(sim.W.env[c, c, sim.layer["fire_mobility"]])
+                assert sim.W.is_burning((c, c)) and (c, c) in sim.W.burning_cells
+            if i % 4 == 3:                    # whole episodes through the single-environment adapter, crossing ones included
+                lo, hi = int(ep.ep_start[i]), int(ep.ep_start[i + 1])
+                for t in range(lo, hi):
+                    state, reward, done, _ = sim.step(int(ep.d["action"][t]))
+                    np.testing.assert_array_equal(state, ep.d["obs"][t].astype(np.float64), err_msg=f"seed {seed} step {t - lo}")
+                    assert reward == ep.d["reward"][t] and done == bool(ep.d["done"][t])
+        assert crossing >= 4
         sim.close()
+
+
+def test_adapter_a_speed_counter_survives_reset_like_the_reference(wf):
+    """METADATA['a_speed_iter'] is module-global in the reference and reset() never touches it (forest_fire.py:40-43,
+    :52-54): with a_speed = 2 an episode with an odd number of steps leaves the next one out of phase.  Ten reference
+    episodes played back to back in ONE adapter object, spawn points from numpy's stream like the reference's."""
+    import random
+    for size in (10, 14):
+        ep = Episodes([f for f in fixture_files(size) if f.endswith("_aspeed2.npz")][0])
+        sim = wf.ForestFire(size=size, metadata={"a_speed": 2, "a_speed_iter": int(ep.a_speed_iter0[0])})
+        phases = set()
+        for i, seed in enumerate(ep.d["seeds"]):
+            np.random.seed(int(seed))
+            random.seed(int(seed))
+            sim.reset()
+            assert sim.METADATA["a_speed_iter"] == ep.a_speed_iter0[i], f"episode {i}: the counter must carry over"
+            phases.add(int(sim.METADATA["a_speed_iter"]))
+            planes, _ = sim._b.download()
+            np.testing.assert_array_equal(planes[0], ep.init_planes[i])
+            lo, hi = int(ep.ep_start[i]), int(ep.ep_start[i + 1])
+            for t in range(lo, hi):
+                state, reward, done, _ = sim.step(int(ep.d["action"][t]))
+                np.testing.assert_array_equal(state, ep.d["obs"][t].astype(np.float64), err_msg=f"episode {i} step {t - lo}")
+                assert reward == ep.d["reward"][t] and done == bool(ep.d["done"][t]), (i, t - lo)
+            planes, _ = sim._b.download()
+            np.testing.assert_array_equal(planes[0], ep.d["planes"][hi - 1])
+        assert phases == {1, 2}
+        sim.close()
+
+
+def test_adapter_without_arguments_shares_the_module_metadata(wf):
+    """ForestFire() works on the package's module-global METADATA like the reference's (forest_fire.py:20): the
+    a_speed counter is shared by every such object; objects built with arguments own a copy."""
+    from wildfire_control_python_amd import constants
+    a, b = wf.ForestFire(), wf.ForestFire()
+    assert a.METADATA is constants.METADATA and b.METADATA is constants.METADATA
+    c = wf.ForestFire(size=10)
+    assert c.METADATA is not constants.METADATA
+    old = dict(constants.METADATA)
+    try:
+        constants.METADATA["a_speed"] = 2
+        constants.METADATA["a_speed_iter"] = 2
+        a.step(5)                                           # counter 2 -> 1: no update
+        assert constants.METADATA["a_speed_iter"] == 1
+        b.step(5)                                           # the OTHER object's step runs the update (counter 1 -> 0 -> 2)
+        assert constants.METADATA["a_speed_iter"] == 2
+        assert a._b.download_envs()["tick"][0] == 0 and b._b.download_envs()["tick"][0] == 1
+    finally:
+        constants.METADATA.clear()
+        constants.METADATA.update(old)
+    for s in (a, b, c):
+        s.close()
 
 
 def test_adapter_string_and_int_actions(wf):
@@ -1276,6 +1415,62 @@ def test_upload_and_kernel_switch_invalidate_reach_boards(wf, monkeypatch, varia
     env.close()
 
 
+@pytest.mark.parametrize("W,H,B", [(256, 256, 6), (15, 15, 300), (13, 11, 257), (30, 23, 64), (51, 47, 33), (64, 70, 17), (100, 150, 5),
+                                   (1, 1, 100), (1, 6, 9), (6, 1, 9), (3, 3, 1), (2, 9, 50), (40, 3, 7), (5, 2000, 2), (24, 24, 40)])
+def test_get_state_kernel_any_shape_any_alignment(wf, W, H, B):
+    """World.get_state() through the LDS-tiled transpose kernel (wf_get_state_cols): shapes that are no multiple of
+    anything, one column per workgroup up to 64, columns that span environments, and output pointers at every
+    byte alignment (a split step hands the kernel `obs + lo * 3 * W * H`)."""
+    import torch
+    env = wf.BatchedForestFire(B, width=W, height=H, containment=False)
+    rng = np.random.default_rng(W * 1000 + H)
+    planes = np.zeros((B, H, W, 4), dtype=np.int8)
+    planes[..., 0] = rng.choice([0, 1, 2, 3, 4], size=(B, H, W), p=[0.5, 0.15, 0.1, 0.15, 0.1])
+    planes[..., 1] = rng.integers(1, 40, size=(B, H, W))
+    planes[..., 3] = rng.random((B, H, W)) < 0.02
+    envs = np.zeros(B, dtype=O.ENV_DTYPE)
+    envs["flags"] = O.F_RUNNING
+    env.upload(planes, envs)
+    want = O.get_state(planes)
+    np.testing.assert_array_equal(env.get_state(), want)
+    n = want.size
+    buf = torch.zeros(n + 16, dtype=torch.int8, device="cuda")
+    for off in (1, 2, 3, 5):
+        buf.fill_(77)
+        torch.cuda.synchronize()
+        env.get_state_device(buf.data_ptr() + off)
+        env.sync()
+        got = buf.cpu().numpy()
+        np.testing.assert_array_equal(got[off:off + n].reshape(want.shape), want, err_msg=f"offset {off}")
+        assert (got[:off] == 77).all() and (got[off + n:] == 77).all(), f"offset {off}: bytes outside the buffer were written"
+    env.close()
+
+
+def test_upload_of_planes_resets_the_wind_counts(wf):
+    """Planes and per-direction heat counts form one state (include/wildfire.h: wf_upload): uploading planes alone starts
+    from zero heat, it never keeps the counts of the grid that was there before."""
+    B, S = 64, 10
+    env = wf.BatchedForestFire(B, size=S, metadata={"wind": [0.85, (1, 0)]})
+    env.reset(seed=3)
+    for _ in range(30):
+        env.step(np.full(B, 5, dtype=np.int8))
+    counts = env.download_counts()
+    assert counts.any()
+    planes, envs = env.download()
+    env.upload(planes, envs)                              # planes only
+    assert not env.download_counts().any()
+    env.upload(planes, envs, counts)                      # a full snapshot: counts restored after the planes
+    np.testing.assert_array_equal(env.download_counts(), counts)
+    # the temp layer of the adapter's World.env is finite everywhere (a cell ignited by accumulated heat reads above the threshold)
+    sim = wf.ForestFire(size=S, metadata={"wind": [0.85, (1, 0)]})
+    for _ in range(40):
+        sim.step(5)
+    temp = sim.W.env[:, :, sim.layer["temp"]]
+    assert np.isfinite(temp).all() and (temp[sim.W.env[:, :, sim.layer["type"]] == 2] > 3).all()
+    sim.close()
+    env.close()
+
+
 def test_api_edge_cases(wf):
     """Odd batch sizes, NULL optional buffers, 64 fused steps, partial uploads, error codes."""
     import ctypes
@@ -1458,20 +1653,20 @@ def test_bench_contract_single_and_two_ranks(wf):
 
 
 # ------------------------------------------------------------------ arbitrary uploaded states
-def _random_state(B, H, W, rng, toggle):
+def _random_state(B, H, W, rng, toggle, rivers=False):
     """Arbitrary (valid) boundary states, not the ones a reset produces: scattered fire with any fuel (0 and 1
     included: burn-out on the first tick), grass at every heat level below ignition, burnt / dirt / water patches,
     with the toggle the two extra codes, agents anywhere (visible or not, digging or not)."""
     planes = np.zeros((B, H, W, 4), dtype=np.int8)
-    kinds = [0, 1, 2, 3, 4] + ([5, 6] if toggle else [])
-    probs = np.array([0.62, 0.10, 0.08, 0.08, 0.06] + ([0.03, 0.03] if toggle else []))
+    kinds = [0, 1, 2, 3, 4] + ([5] if toggle else []) + ([6] if toggle or rivers else []) + ([13] if rivers else [])
+    probs = np.array([0.62, 0.10, 0.08, 0.08, 0.06] + ([0.03] if toggle else []) + ([0.03] if toggle or rivers else []) + ([0.03] if rivers else []))
     t = rng.choice(kinds, size=(B, H, W), p=probs / probs.sum()).astype(np.int8)
     t[:, 0, 0] = np.where(t[:, 0, 0] == 4, 0, t[:, 0, 0])          # (a place for the agent even on a 1x1 grid)
     fuel = rng.integers(1, 45, size=(B, H, W))
-    burning = (t == 1) | (t == 5)
+    burning = (t == 1) | (t == 5) | (t == 13)
     fuel[burning] = rng.integers(-3, 30, size=int(burning.sum()))     # <= 0: poked states only, burn out at once
     heat = rng.integers(0, 19, size=(B, H, W))
-    heat[t == 1] = rng.choice([19, 25], size=int((t == 1).sum()))
+    heat[(t == 1) | (t == 13)] = rng.choice([19, 25], size=int(((t == 1) | (t == 13)).sum()))
     planes[..., 0], planes[..., 1], planes[..., 2] = t, fuel, heat
     envs = np.zeros(B, dtype=O.ENV_DTYPE)
     for b in range(B):
@@ -1493,17 +1688,26 @@ def _random_state(B, H, W, rng, toggle):
                                         (64, 70, False), (11, 13, True),
                                         # grids too small for World.reset()'s spawn circle: uploaded states only
                                         (5, 4, True), (3, 3, False), (1, 6, False), (6, 1, True), (2, 9, False), (1, 1, False),
-                                        (4, 4, True), (40, 3, False), (36, 30, True), (100, 70, True), (51, 47, False)])
+                                        (4, 4, True), (40, 3, False), (36, 30, True), (100, 70, True), (51, 47, False),
+                                        # make_rivers contexts: blocked fire cells (code 13) anywhere, with and without the toggle
+                                        (14, 14, "rivers"), (10, 10, "both"), (12, 12, "rivers"), (16, 16, "both"), (32, 32, "rivers"),
+                                        (11, 13, "both"), (64, 70, "rivers"), (100, 70, "both")])
 def test_arbitrary_uploaded_states_match_oracle(wf, W, H, toggle):
     """Parity on states no reset would produce (uploaded through wf_upload): every kernel family, with and without
-    the dig toggle, 40 steps of random actions from each of several random states."""
+    the dig toggle / rivers, 40 steps of random actions from each of several random states."""
     B = 320
-    md = {"allow_dig_toggle": True, "n_actions": 5} if toggle else None
-    env = wf.BatchedForestFire(B, width=W, height=H, containment=True, metadata=md)
-    op = O.default_params(allow_dig_toggle=int(toggle), containment=1)
+    rivers = toggle in ("rivers", "both")
+    toggle = toggle is True or toggle == "both"
+    md = {}
+    if toggle:
+        md.update({"allow_dig_toggle": True, "n_actions": 5})
+    if rivers:
+        md["make_rivers"] = True
+    env = wf.BatchedForestFire(B, width=W, height=H, containment=True, metadata=md or None)
+    op = O.default_params(allow_dig_toggle=int(toggle), containment=1, make_rivers=int(rivers))
     rng = np.random.default_rng(W * 131 + H)
     for rep in range(3):
-        planes, envs = _random_state(B, H, W, rng, toggle)
+        planes, envs = _random_state(B, H, W, rng, toggle, rivers)
         env.upload(planes, envs)
         for t in range(40):
             a = rng.integers(0, 6, size=B).astype(np.int8)

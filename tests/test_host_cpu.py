@@ -264,3 +264,40 @@ def test_bench_labels_name_the_config_they_are():
     assert bench.config_label(14, 16384, False, 0) == "custom size"
     ref = bench.reference_python_numbers(14)      # written by tools/time_reference.py from the real reference
     assert ref and ref["grid"] == 14 and 1e5 < ref["cell_updates_per_s_1_process"] < 1e8
+
+
+def test_wind_parameters_that_counts_cannot_decide_are_refused():
+    """wf_create checks a wind with a direction before it looks for a device (include/wildfire.h, wf_params.wind_mode):
+    addends so small that a count byte would saturate before the threshold is reached, or a reachable heat sum within
+    rounding distance of the threshold, are WF_ERR_UNSUPPORTED (-2); sound parameters get as far as the device probe."""
+    import ctypes
+    from wildfire_control_python_amd import _native as N
+    lib = N.lib()
+
+    def create(**kw):
+        p = N.default_params()
+        p.wind_mode = N.WIND_FIXED
+        p.wind_code = N.wind_code(1, 0, 0)
+        p.wind_speed[0] = 0.85
+        for k, v in kw.items():
+            if k == "speed":
+                p.wind_speed[0] = v
+            else:
+                setattr(p, k, v)
+        h = ctypes.c_void_p()
+        rc = lib.wf_create(ctypes.byref(h), 0, 8, 10, 10, ctypes.byref(p))
+        if rc == 0:
+            lib.wf_destroy(h)
+        return rc
+
+    ok = create()
+    assert ok in (0, -3), ok                              # fine: a context, or "no device" on the CPU box
+    assert create(speed=0.01) == -2                       # 3 / (0.01 * 0.3 / (pi + 1)) = 4 142 addends: a count byte saturates at 255
+    assert create(speed=1.0, heat=0.5, threshold=3.0) == -2      # six addends of 0.5 sum to the threshold exactly
+    p = N.default_params()
+    p.wind_mode = N.WIND_RANDOM                           # the reference's own "random" winds are sound
+    h = ctypes.c_void_p()
+    rc = lib.wf_create(ctypes.byref(h), 0, 8, 10, 10, ctypes.byref(p))
+    assert rc in (0, -3), rc
+    if rc == 0:
+        lib.wf_destroy(h)

@@ -52,9 +52,12 @@ def river_histograms(water):
 
 def check_rivers(water, size):
     ref = ref_stats(size)
-    assert not water[:, size // 2, size // 2].any(), "a river through the fire cell must have been redrawn"
     for k, h in river_histograms(water).items():
         same_law(h, ref[k], f"river {k} ({size}x{size})")
+    # rivers through the fire cell (the reference: 8-16 %): same rate
+    cross = int(water[:, size // 2, size // 2].sum())
+    same_law([cross, len(water) - cross], [int(ref["n_crossing"]), int(ref["n_rivers"]) - int(ref["n_crossing"])],
+             f"rivers through the fire cell ({size}x{size})")
 
 
 def spawn_counts(x, y, size):
@@ -91,17 +94,24 @@ def test_reset_with_rivers_oracle_layout():
     planes, envs = O.new_state(B, S, S)
     O.reset(planes, envs, seed=9, params=O.default_params(make_rivers=1))
     t = planes[..., 0]
-    assert (t[:, S // 2, S // 2] == 1).all()
+    full = np.stack([O.river(S, S, seed=9, env_id=i, episode=0) for i in range(B)]).astype(bool)
+    crossed = full[:, S // 2, S // 2]
+    assert 0.04 < crossed.mean() < 0.2
+    # the fire cell: plain fire, or - under a river - fire with infinite fire mobility (set_fire_to after reset_map)
+    np.testing.assert_array_equal(t[:, S // 2, S // 2], np.where(crossed, 13, 1))
     y, x = envs["y"].astype(int), envs["x"].astype(int)
     assert (t[np.arange(B), y, x] == 3).all()
-    n_water = (t == 4).reshape(B, -1).sum(axis=1)
+    n_water = ((t == 4) | (t == 13)).reshape(B, -1).sum(axis=1)
     assert n_water.min() >= S - 7 and n_water.max() <= S - 2
-    water = t == 4
+    water = (t == 4) | (t == 13)
     # spawn on the river: the river shows a one-cell gap there
-    full = np.stack([O.river(S, S, seed=9, env_id=i, episode=0) for i in range(64)]).astype(bool)
     for i in range(64):
         gap = full[i] & ~water[i]
         assert gap.sum() == int(full[i, y[i], x[i]]) and (gap.sum() == 0 or gap[y[i], x[i]])
+    # the observation shows a blocked fire cell as fire, and as blocked (environment.py:399-402)
+    obs = O.get_state(planes)
+    i = int(np.nonzero(crossed)[0][0])
+    assert obs[i, S // 2, S // 2, 1] == 1 and obs[i, S // 2, S // 2, 2] == 0
 
 
 # ----------------------------------------------------------------------------- HIP
@@ -122,6 +132,8 @@ def test_device_reset_with_rivers_equals_oracle(monkeypatch, W, H, B):
     gp, ge = env.download()
     np.testing.assert_array_equal(gp, planes, err_msg="reset planes")
     assert (gp[..., 0] == 4).any()
+    if B >= 500:
+        assert (gp[..., 0] == 13).any(), "some river must run through the fire cell"
     rng = np.random.default_rng(W * H)
     resets = paid = 0
     vis = np.uint16(~np.uint16(128 | 256))
@@ -161,7 +173,7 @@ def test_device_reset_laws_match_the_reference(size):
     ref = ref_stats(size)
     same_law(spawn_counts(envs["x"], envs["y"], size), ref["spawn"], f"device spawn point ({size}x{size})")
     # the river, spawn cell put back (the agent dug it): compare with the stand-alone river of the same stream
-    water = planes[:30000, :, :, 0] == 4
+    water = (planes[:30000, :, :, 0] == 4) | (planes[:30000, :, :, 0] == 13)
     y, x = envs["y"][:30000].astype(int), envs["x"][:30000].astype(int)
     full = water.copy()
     for i in range(len(full)):

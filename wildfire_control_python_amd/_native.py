@@ -19,6 +19,8 @@ assert ENV_DTYPE.itemsize == 16
 
 P_TYPE, P_FUEL, P_HEAT, P_AGENT = 0, 1, 2, 3
 GRASS, FIRE, BURNT, DIRT, WATER = 0, 1, 2, 3, 4
+DIRT_BURNING, BURNT_BLOCKED = 5, 6   # allow_dig_toggle only: dig() on a burning cell (include/wildfire.h)
+FIRE_BLOCKED = 13                    # make_rivers only: the river under the fire cell (type fire, fire_mobility inf)
 HEAT_FORCED = 25
 HEAT_IGNITED = 24          # wind with a direction: plane 2 of a cell ignited by accumulated heat
 WIND_CALM, WIND_FIXED, WIND_RANDOM = 0, 1, 2

@@ -36,9 +36,16 @@ class BatchedForestFire:
     def __init__(self, batch, size=None, *, width=None, height=None, device=0, metadata=None,
                  seed=0, env_id0=0, auto_reset=False, fuel_range=None, ignite_ppm=0,
                  containment=None):
-        self.METADATA = dict(_DEFAULT_METADATA)
-        if metadata:
-            self.METADATA.update(metadata)
+        if metadata is _DEFAULT_METADATA:
+            # the module-global dict itself (the single-environment adapter with no arguments): shared by every such
+            # object of the process, like the reference's METADATA (forest_fire.py:20, constants.py:30-57)
+            self.METADATA = metadata
+        else:
+            self.METADATA = dict(_DEFAULT_METADATA)
+            if metadata:
+                self.METADATA.update(metadata)
+                if "a_speed" in metadata and "a_speed_iter" not in metadata:
+                    self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]    # constants.py:42-43: both are A_SPEED
         if size is not None:
             width = height = size
         if width is not None:
@@ -151,11 +158,11 @@ class BatchedForestFire:
         """Replace device state.  planes int8 (batch,H,W,4); envs _native.ENV_DTYPE (batch,).
         When envs is omitted it is derived from the planes the way Agent.__init__ does
         (environment.py:103-109): the agent is where the agent_pos plane says.
-        counts (wind with a direction only): uint8 (batch,H,W,4) heat addends received per direction."""
+        counts (wind with a direction only): uint8 (batch,H,W,4) heat addends received per direction; planes without
+        counts start from zero heat (the old grid's counts are never kept)."""
         if counts is not None:
             counts = np.ascontiguousarray(counts, dtype=np.uint8)
             assert counts.shape == (self.batch, self.height, self.width, 4), counts.shape
-            self._ck(self._lib.wf_wind_counts_upload(self._h, N.ptr(counts)), "wf_wind_counts_upload")
         if planes is not None:
             planes = np.ascontiguousarray(planes, dtype=np.int8)
             assert planes.shape == (self.batch, self.height, self.width, 4), planes.shape
@@ -164,7 +171,12 @@ class BatchedForestFire:
         if envs is not None:
             envs = np.ascontiguousarray(envs, dtype=N.ENV_DTYPE)
             assert envs.shape == (self.batch,)
-        self._ck(self._lib.wf_upload(self._h, N.ptr(planes), N.ptr(envs)), "wf_upload")
+        if planes is not None or envs is not None:
+            self._ck(self._lib.wf_upload(self._h, N.ptr(planes), N.ptr(envs)), "wf_upload")
+        # planes and counts form ONE state: wf_upload of planes zeroes the counts (a new grid has received no heat),
+        # so the counts of a snapshot go up after its planes
+        if counts is not None:
+            self._ck(self._lib.wf_wind_counts_upload(self._h, N.ptr(counts)), "wf_wind_counts_upload")
 
     def download(self):
         planes = np.empty((self.batch, self.height, self.width, 4), dtype=np.int8)
@@ -215,7 +227,7 @@ class BatchedForestFire:
         idx = ag.reshape(self.batch, -1).argmax(axis=1)
         envs["x"] = np.where(has, idx % self.width, 0)
         envs["y"] = np.where(has, idx // self.width, 0)
-        fire = (planes[..., N.P_TYPE] == N.FIRE).reshape(self.batch, -1).any(axis=1)
+        fire = ((planes[..., N.P_TYPE] & 3) == 1).reshape(self.batch, -1).any(axis=1)     # burning_cells non-empty
         envs["flags"] = (has * (N.F_ALIVE | N.F_VISIBLE | N.F_DIGGING)) | ((has & fire) * N.F_RUNNING)
         return envs
 
@@ -231,7 +243,8 @@ class BatchedForestFire:
             assert mask.shape == (self.batch,)
         self._ck(self._lib.wf_reset(self._h, N.ptr(mask), ctypes.c_uint64(int(seed) & (2**64 - 1))),
                  "wf_reset")
-        self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
+        # (METADATA['a_speed_iter'] is NOT re-armed: the reference's reset() never touches it, forest_fire.py:52-54 -
+        # with a_speed > 1 an episode that ends mid-cycle leaves the next one out of phase, there as here)
         return self.get_state()
 
     def reset_host(self, spawns=None, rng=np.random, pyrng=None):
@@ -257,15 +270,15 @@ class BatchedForestFire:
                 envs[b]["wind"] = N.wind_code(pyrng.randint(-1, 1), pyrng.randint(-1, 1), si)
             if self.METADATA["make_rivers"]:
                 self._make_river(planes[b], rng)          # drawn BEFORE the spawn point, as reset_map does
-                planes[b, fy, fx, N.P_TYPE] = N.FIRE       # set_fire_to retypes the centre afterwards
+                # set_fire_to retypes the centre afterwards; under a river its fire_mobility stays inf (:85, :241)
+                planes[b, fy, fx, N.P_TYPE] = N.FIRE_BLOCKED if planes[b, fy, fx, N.P_TYPE] == N.WATER else N.FIRE
             sx, sy = spawns[b] if spawns is not None else get_agent_location(W, H, rng)
             planes[b, sy, sx, N.P_AGENT] = 1                               # Agent.__init__ :108-113
             planes[b, sy, sx, N.P_TYPE] = N.DIRT
             envs[b]["x"], envs[b]["y"] = sx, sy
         envs["flags"] = N.F_ALIVE | N.F_VISIBLE | N.F_DIGGING | N.F_RUNNING
         self.upload(planes, envs, np.zeros(planes.shape, np.uint8) if self.wind_mode != N.WIND_CALM else None)
-        self.METADATA["a_speed_iter"] = self.METADATA["a_speed"]
-        return self.get_state()
+        return self.get_state()               # (a_speed_iter survives a reset, as in the reference: see reset())
 
     def _make_river(self, p, rng):
         """The reference's river generator (reset_map, environment.py:69-95), draw for draw on

@@ -1,7 +1,7 @@
 """Simulation constants: same keys and defaults as the reference's METADATA dict
 (Simulation/constants.py:26-57), so learners that read sim.METADATA keep working.
-Unlike the reference, every environment object owns a COPY (the reference shares
-one module-global dict that step() mutates, forest_fire.py:40-43)."""
+ForestFire() without arguments works on THIS dict, like the reference (one module-global dict that step()
+mutates, forest_fire.py:40-43); BatchedForestFire and ForestFire(metadata=..., size=...) take a private copy."""
 
 SIZE = 10
 A_SPEED = 1

@@ -5,7 +5,10 @@
 // wf_kernels.hip on the context's HIP stream.  There is NO CPU fallback: without a
 // usable HIP device wf_create fails with WF_ERR_NO_DEVICE.
 #include <math.h>
+#include <atomic>
 #include <new>
+#include <thread>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -113,6 +116,87 @@ bool params_ok(const wf_params *p)
         if (!(p->heat > 0.0) || !(p->threshold > 0.0) || !isfinite(p->heat) || !isfinite(p->threshold)) return false;
     }
     return true;
+}
+
+// Wind with a direction: the kernels decide `temp > threshold` from per-direction COUNTS of addends (one byte each)
+// and the float64 sum of count x addend; the reference adds the addends one by one in the iteration order of a Python
+// set.  Both decide alike as long as (a) no count a cell can reach before it ignites exceeds 255 and (b) no reachable
+// sum comes within rounding distance of the threshold.  Checked here for every wind the context can meet (the fixed
+// code, or the 27 winds "random" draws): parameters that fail are refused (WF_ERR_UNSUPPORTED), not approximated.
+int wind_params_status(const wf_params *p)
+{
+    if (p->wind_mode == WF_WIND_CALM) return WF_OK;
+    static const int dcx[4] = { 0, 0, 1, -1 }, dcy[4] = { -1, 1, 0, 0 };
+    const double T = p->threshold, margin = 1e-9 * (T > 1.0 ? T : 1.0);
+    for (int si = 0; si < (p->wind_mode == WF_WIND_RANDOM ? 3 : 1); ++si)
+        for (int v = 0; v < (p->wind_mode == WF_WIND_RANDOM ? 9 : 1); ++v) {
+            int wxi, wyi, s = si;
+            if (p->wind_mode == WF_WIND_RANDOM) { wxi = v % 3 - 1; wyi = v / 3 - 1; }
+            else { wxi = (p->wind_code & 3) - 1; wyi = ((p->wind_code >> 2) & 3) - 1; s = (p->wind_code >> 4) & 3; }
+            const double speed = p->wind_speed[s];
+            if (!(speed > 0.0)) continue;                    // no heat at all: nothing ever ignites
+            // distinct addends and how many directions share each (an axis wind: 1 + 2 + 1, a diagonal one: 2 + 2)
+            double cv[4];
+            int mult[4], nv = 0;
+            for (int k = 0; k < 4; ++k) {
+                const double wx = wxi, wy = wyi, cx = dcx[k], cy = dcy[k];
+                const double angle = fabs(atan2(wx * cy - wy * cx, wx * cx + wy * cy));
+                const double ck = speed * p->heat * pow(angle + 1.0, -1.0);
+                int j = 0;
+                while (j < nv && cv[j] != ck) ++j;
+                if (j == nv) { cv[nv] = ck; mult[nv] = 0; ++nv; }
+                ++mult[j];
+            }
+            long long top[4] = { 0, 0, 0, 0 }, combos = 1;
+            for (int j = 0; j < nv; ++j) {
+                const double per_dir = floor(T / cv[j]) + 1.0;          // addends of this size until the sum exceeds T
+                if (!(per_dir <= 255.0)) return WF_ERR_UNSUPPORTED;      // a count byte would saturate first
+                top[j] = (long long)per_dir * mult[j];
+                combos *= top[j] + 1;
+            }
+            if (combos > 50000000ll) return WF_ERR_UNSUPPORTED;
+            for (long long n0 = 0; n0 <= top[0]; ++n0)
+                for (long long n1 = 0; n1 <= top[1]; ++n1)
+                    for (long long n2 = 0; n2 <= top[2]; ++n2)
+                        for (long long n3 = 0; n3 <= top[3]; ++n3) {
+                            const double sum = (double)n0 * cv[0] + (nv > 1 ? (double)n1 * cv[1] : 0.0) +
+                                               (nv > 2 ? (double)n2 * cv[2] : 0.0) + (nv > 3 ? (double)n3 * cv[3] : 0.0);
+                            if (fabs(sum - T) < margin) return WF_ERR_UNSUPPORTED;
+                        }
+        }
+    return WF_OK;
+}
+
+// Every cell type of an upload is one this context's kernels know: bit t of `allowed`.
+bool types_ok(const wf_ctx *c, const int8_t *planes)
+{
+    uint32_t allowed = (1u << WF_GRASS) | (1u << WF_FIRE) | (1u << WF_BURNT) | (1u << WF_DIRT) | (1u << WF_WATER);
+    if (c->p.allow_dig_toggle) allowed |= (1u << WF_DIRT_BURNING) | (1u << WF_BURNT_BLOCKED);
+    if (c->p.make_rivers) allowed |= (1u << WF_FIRE_BLOCKED) | (1u << WF_BURNT_BLOCKED);
+    const size_t n = (size_t)c->batch * c->H * c->W;
+    auto scan = [planes, allowed](size_t lo, size_t hi) -> uint32_t {
+        uint32_t bad = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint32_t t = (uint8_t)planes[4 * i];
+            bad |= (t > 15u ? 1u : 0u) | (((allowed >> (t & 15u)) & 1u) ^ 1u);
+        }
+        return bad;
+    };
+    const size_t per_thread = (size_t)1 << 22;
+    if (n <= 2 * per_thread) return scan(0, n) == 0;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 2) nt = 2;
+    if (nt > 16) nt = 16;
+    std::atomic<uint32_t> bad(0);
+    std::vector<std::thread> pool;
+    const size_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo >= hi) break;
+        pool.emplace_back([&, lo, hi] { bad.fetch_or(scan(lo, hi)); });
+    }
+    for (auto &th : pool) th.join();
+    return bad.load() == 0;
 }
 
 // World.reset() puts the agent on a circle of radius 1..3 around the centre (utility.py:66-78; the reference asserts
@@ -314,6 +398,7 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     wf_params pp;
     if (p) pp = *p; else wf_default_params(&pp);
     if (!params_ok(&pp)) return WF_ERR_ARG;
+    if (wind_params_status(&pp) != WF_OK) return WF_ERR_UNSUPPORTED;
     // wind with a direction is served by the thread-per-cell family, whatever the shape
     // (WF_FAMILY=cells / tiled, experiments and tests: the generic family for a shape another family would serve, the
     // tiled family for a small grid)
@@ -440,6 +525,7 @@ int wf_destroy(wf_ctx *c)
 int wf_set_params(wf_ctx *c, const wf_params *p)
 {
     if (!c || !p || !params_ok(p)) return WF_ERR_ARG;
+    if (wind_params_status(p) != WF_OK) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_CELLS && p->containment && (long long)c->H * c->W > WF_CELLS_FLOOD_MAX) return WF_ERR_UNSUPPORTED;
     if (c->fam == WF_FAM_TILED && p->containment && c->H > 1024) return WF_ERR_UNSUPPORTED;
     if (p->make_rivers && !rivers_ok(c->fam, c->H, c->W)) return WF_ERR_UNSUPPORTED;
@@ -476,23 +562,16 @@ int wf_upload(wf_ctx *c, const int8_t *planes, const wf_env *envs)
     if (envs)
         for (int i = 0; i < c->batch; ++i)
             if (envs[i].x >= c->W || envs[i].y >= c->H) return WF_ERR_ARG;
-    // ... and so is a cell type the kernels do not know (codes 5 / 6 exist only with allow_dig_toggle, see wildfire.h)
-    if (planes) {
-        const size_t n = (size_t)c->batch * c->H * c->W;
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(planes);
-        const uint32_t top = c->p.allow_dig_toggle ? (uint32_t)WF_BURNT_BLOCKED : (uint32_t)WF_WATER;
-        uint32_t bad = 0;
-        if ((reinterpret_cast<uintptr_t>(planes) & 3u) == 0) {
-            for (size_t i = 0; i < n; ++i) bad |= (w[i] & 0xffu) > top ? 1u : 0u;
-        } else {
-            for (size_t i = 0; i < n; ++i) bad |= (uint32_t)(uint8_t)planes[4 * i] > top ? 1u : 0u;
-        }
-        if (bad) return WF_ERR_ARG;
-    }
+    // ... and so is a cell type the context's kernels do not know (codes 5 / 6 exist only with allow_dig_toggle, 13 / 6
+    // only with make_rivers, see wildfire.h).  Large uploads are checked by several host threads (the scalar loop cost
+    // 0.1 s per upload of the 1 M-environment configuration).
+    if (planes && !types_ok(c, planes)) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     const size_t cells = (size_t)c->batch * c->H * c->W;
     if (planes) HIP_TRY(c, hipMemcpyAsync(c->planes, planes, cells * 4, hipMemcpyHostToDevice, c->stream));
+    // planes and heat counts form ONE state: a new grid has received no heat until wf_wind_counts_upload says otherwise
+    if (planes && c->wind_cnt) HIP_TRY(c, hipMemsetAsync(c->wind_cnt, 0, cells * 4, c->stream));
     if (envs) HIP_TRY(c, hipMemcpyAsync(c->envs, envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyHostToDevice, c->stream));
     if (planes || envs) HIP_TRY(c, wf_launch_invalidate_reach(c->envs, c->batch, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -58,7 +58,8 @@ __device__ __forceinline__ uint32_t reset_cell(const ResetLaw &L, const EnvKey &
     if (L.span > 1u) fuel += below(key.draw(16u + q), L.span);
     uint32_t ty = WF_GRASS, heat = 0, ag = 0;
     if (river_col == x) ty = WF_WATER;
-    if (q == L.qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }                 // set_fire_to :233-246
+    // set_fire_to :233-246; under a river the cell keeps its infinite fire mobility (:85)
+    if (q == L.qc) { ty = ty == WF_WATER ? (uint32_t)WF_FIRE_BLOCKED : (uint32_t)WF_FIRE; heat = WF_HEAT_FORCED; }
     if (q == L.qs) { ty = WF_DIRT; ag = 1; }                                // Agent.__init__ :108-113
     if (L.ppm && ty == WF_GRASS && below(key.draw(16u + L.cells + q), 1000000u) < L.ppm) {
         ty = WF_FIRE;
@@ -97,7 +98,7 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
     uint32_t qd = inb ? ny * W + nx : qa;
     const uint32_t td = pe[(size_t)qd * 4], tcur = pe[(size_t)qa * 4];
     const uint32_t moved = inb & (td != WF_WATER ? 1u : 0u);                          // :146 traversable
-    const uint32_t dfire = moved & (td == WF_FIRE ? 1u : 0u);
+    const uint32_t dfire = moved & (FIRE_SET >> td) & 1u;                             // is_burning(): fire, blocked fire
     uint32_t dug = moved & ((fl >> 2) & 1u) & (DIG_SET >> td) & 1u;                   // :151-152, :125-133
     uint32_t dugtype = WF_DIRT;
     const uint32_t vis_before = (fl >> 1) & 1u;
@@ -107,13 +108,13 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
     if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && act == 4u) {                              // forest_fire.py:35-36
         fl ^= WF_F_DIGGING;
         // dig() under the agent: a BURNING cell too, which keeps burning under its new type (WF_DIRT_BURNING)
-        dug = ((fl >> 2) & 1u) & ((DIG_SET | 2u) >> tcur) & 1u;
-        if (tcur == WF_FIRE) dugtype = WF_DIRT_BURNING;
+        dug = ((fl >> 2) & 1u) & ((DIG_SET | FIRE_SET) >> tcur) & 1u;
+        if ((FIRE_SET >> tcur) & 1u) dugtype = WF_DIRT_BURNING;
         qd = qa;
     }
     if (dug) ta = WF_DIRT;
     if (a.update_mask & 1ull) {                                                        // forest_fire.py:87
-        const uint32_t dies = (fl & 1u) & (((fl >> 3) & 1u) | (ta == WF_FIRE ? 1u : 0u));
+        const uint32_t dies = (fl & 1u) & (((fl >> 3) | (FIRE_SET >> ta)) & 1u);
         if (dies) fl &= ~(uint32_t)(WF_F_ALIVE | WF_F_VISIBLE);
     }
     // containment bookkeeping (same exact rule as wf_step_group's phase A): can this dig change
@@ -132,7 +133,7 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
                 if (rx < W && ry < H) {
                     const uint32_t ty = pe[(size_t)(ry * W + rx) * 4];
                     if (ty < WF_DIRT) ring |= 1u << r;
-                    if (ty == WF_DIRT_BURNING && !(r & 1)) zn = true;      // burning dirt hangs on the board through its neighbours
+                    if (blocked_burning(ty) && !(r & 1)) zn = true;        // burning dirt / blocked fire hangs on the board through its neighbours
                     if (!(r & 1) && (rx == 0 || ry == 0 || rx == W - 1 || ry == H - 1)) bn |= 1u << r;
                 }
             }

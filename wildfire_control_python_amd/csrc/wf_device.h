@@ -81,19 +81,18 @@ struct EnvKey {
 // ----------------------------------------------------------------------------
 // Same law as oracle/wf_oracle.c wfo_river (written independently): start column uniform, start row in {1,2,3}, one
 // water cell per row, the column drifting by +-1 under the reference's acceptance test, the walk ending H - {1,2,3}
-// rows down; a river through the fire cell is redrawn (up to 7 times; the 8th is taken minus that cell).  Every lane
-// of a wave holds the same key, so the walk is wave-uniform control flow.  mark(x, y) is called for every water cell.
+// rows down.  The walk may pass through the fire cell (the reference's does in 8-16 % of its resets): mark() is called
+// for that cell too, and the reset makes it WF_FIRE_BLOCKED.  Every lane of a wave holds the same key, so the walk is
+// wave-uniform control flow.  mark(x, y) is called for every river cell.
 template <class F>
-__device__ __forceinline__ bool river_attempt(const EnvKey &key, int W, int H, uint32_t attempt, F &&mark)
+__device__ __forceinline__ void river_cells(const EnvKey &key, int W, int H, F &&mark)
 {
-    uint32_t n = 0x80000000u + attempt * 0x10000u;
+    uint32_t n = 0x80000000u;
     const int fx = W / 2, fy = H / 2;                        // utility.py:61-64
-    bool crossed = false;
     int x = (int)below(key.draw(n++), (uint32_t)W);          // :75
     int y = 1 + (int)below(key.draw(n++), 3u);               // :77
     while (y < H - (1 + (int)below(key.draw(n++), 3u))) {    // :79
-        if (x == fx && y == fy) crossed = true;
-        else mark(x, y);                                     // :81-87
+        mark(x, y);                                          // :81-87
         const int ny = y + 1;
         int nx = x, tries = 0;
         bool ok = false;
@@ -107,16 +106,6 @@ __device__ __forceinline__ bool river_attempt(const EnvKey &key, int W, int H, u
         x = nx;
         y = ny;
     }
-    return !crossed;
-}
-
-template <class F>
-__device__ __forceinline__ void river_cells(const EnvKey &key, int W, int H, F &&mark)
-{
-    uint32_t attempt = 0;
-    for (; attempt < 7u; ++attempt)
-        if (river_attempt(key, W, H, attempt, [](int, int) {})) break;
-    river_attempt(key, W, H, attempt, mark);
 }
 
 // move table, 6 bits per action 0..4: (dx+1) | (dy+1)<<2 | is_move<<4; entry 4 = "no move"
@@ -126,10 +115,26 @@ constexpr uint32_t MOVE_LUT = (1u | 0u << 2 | 16u) | (1u | 2u << 2 | 16u) << 6 |
 
 // cell types dig() turns into dirt on a MOVE (environment.py:151-152: not burning; :127: not dirt already):
 // grass, burnt, blocked burnt.  Bit t of the set = type t.  toggle_digging() digs under the agent without the
-// "not burning" guard: DIG_SET | fire.
+// "not burning" guard: DIG_SET | FIRE_SET.
 constexpr uint32_t DIG_SET = (1u << WF_GRASS) | (1u << WF_BURNT) | (1u << WF_BURNT_BLOCKED);
+// cell types World.is_burning() is true for (type == fire, environment.py:249-251): plain fire and the fire cell a
+// river was drawn under (WF_FIRE_BLOCKED).  An agent that steps on one dies; observation plane 1 shows them.
+constexpr uint32_t FIRE_SET = (1u << WF_FIRE) | (1u << WF_FIRE_BLOCKED);
+// a cell that burns but blocks the containment search (fire_mobility inf): WF_DIRT_BURNING (5) or WF_FIRE_BLOCKED (13).
+// The reference's A* still STARTS from such a cell: it reaches the border iff one of its 4-neighbours does.
+__device__ __forceinline__ bool blocked_burning(uint32_t type) { return (type & 7u) == 5u; }
+// The fire step of a packed cell word: low half + 0xFF00 (fuel - 1) while the cell keeps burning, + 0xFF01 (type + 1:
+// fire -> burnt, burning dirt -> blocked burnt) when it burns out.  A blocked fire cell (13) burns out to blocked burnt
+// (6, not 14): 8 less.  Only the instantiations that know those codes (RARE) pay the two instructions.
+template <bool RARE>
+__device__ __forceinline__ uint32_t burn_out_step(uint32_t c)
+{
+    if constexpr (RARE) return 0x0000FF01u - (c & 8u);
+    else return 0x0000FF01u;
+}
 
-// "burning" test on a packed cell word.  With the dig toggle a burning cell is WF_FIRE or WF_DIRT_BURNING: (type & 3) == 1.
+// "burning" test on a packed cell word.  With the dig toggle / rivers a burning cell is WF_FIRE, WF_DIRT_BURNING or
+// WF_FIRE_BLOCKED: (type & 3) == 1.
 // Without it (RARE = false) those codes cannot arise and the plain byte compare is one instruction (SDWA) and no
 // temporary register.
 template <bool RARE>

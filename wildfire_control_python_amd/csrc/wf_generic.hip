@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void wf_cells_flood(const WfArgs a, const uint
     uint8_t *out = reinterpret_cast<uint8_t *>(a.reach) + (size_t)e * cells;
     for (uint32_t q = threadIdx.x; q < cells; q += 256u) {
         uint8_t v = board[q] >> 1;
-        if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (se[q] & 0xffu) == (uint32_t)WF_DIRT_BURNING) {
-            // burning dirt: impassable, but the reference's search starts from it -> reached iff a 4-neighbour is
+        if ((a.hot_flags & WF_HOT_RARE) && blocked_burning(se[q])) {
+            // burning dirt / blocked fire: impassable, but the reference's search starts from it -> reached iff a 4-neighbour is
             const uint32_t x = q % W, y = q / W;
             v = ((x > 0 && board[q - 1] == 3) || (x + 1 < W && board[q + 1] == 3) ||
                  (y > 0 && board[q - W] == 3) || (y + 1 < H && board[q + W] == 3)) ? 1 : 0;
@@ -105,7 +105,8 @@ __device__ __forceinline__ uint32_t cell_tick(uint32_t c, uint32_t nN, uint32_t 
     const uint32_t t = c & 0xffu;
     ig = 0;
     if ((t & 3u) == 1u) {                                                  // burning: fire or burning dirt
-        c = (c & 0xFFFF0000u) | ((c + 0xFF01u - still(c)) & 0xFFFFu);      // reduce_fuel :297-307 (low half only)
+        // reduce_fuel :297-307 (low half only): fuel - 1, and type + 1 when it burns out (blocked fire 13 -> blocked burnt 6)
+        c = (c & 0xFFFF0000u) | ((c + (still(c) ? 0xFF00u : burn_out_step<true>(c))) & 0xFFFFu);
     } else if (t == WF_GRASS) {
         // get_neighbours :311-326.  Direction k of the vector burning cell -> this cell: the cell below heats
         // it northwards (k = 0), the one above southwards (1), the left one eastwards (2), the right one westwards (3)
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
             for (uint32_t q = t; q < cells; q += NT) {
                 const uint32_t y = q / W, x = q - y * W;
                 uint32_t v = reached(x, y);
-                if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (src(q) & 0xffu) == (uint32_t)WF_DIRT_BURNING)     // reached iff a 4-neighbour is
+                if ((a.hot_flags & WF_HOT_RARE) && blocked_burning(src(q)))     // burning dirt / blocked fire: reached iff a 4-neighbour is
                     v = ((x > 0 && reached(x - 1, y)) || (x + 1 < W && reached(x + 1, y)) || (y > 0 && reached(x, y - 1)) || (y + 1 < H && reached(x, y + 1))) ? 1u : 0u;
                 reach_e[q] = (uint8_t)v;
                 if constexpr (STAGE) board[q] = (uint8_t)(v << 2);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 
             }
             for (uint32_t q = t; q < cells; q += NT) {
                 uint32_t v = (board[q] & 3u) >> 1;
-                if ((a.hot_flags & WF_HOT_DIG_TOGGLE) && (src(q) & 0xffu) == (uint32_t)WF_DIRT_BURNING) {
+                if ((a.hot_flags & WF_HOT_RARE) && blocked_burning(src(q))) {
                     const uint32_t x = q % W, y = q / W;
                     v = ((x > 0 && (board[q - 1] & 3u) == 3u) || (x + 1 < W && (board[q + 1] & 3u) == 3u) ||
                          (y > 0 && (board[q - W] & 3u) == 3u) || (y + 1 < H && (board[q + W] & 3u) == 3u)) ? 1u : 0u;

@@ -130,7 +130,8 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
         int32_t fuel = fuel_lo;
         if (span > 1u) fuel += (int32_t)below(key.draw(16u + q), span);
         uint32_t ty = ((water >> j) & 1u) ? (uint32_t)WF_WATER : (uint32_t)WF_GRASS, heat = 0;
-        if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }         // set_fire_to :233-246
+        // set_fire_to :233-246; under a river the cell keeps its infinite fire mobility (:85)
+        if (q == qc) { ty = ty == (uint32_t)WF_WATER ? (uint32_t)WF_FIRE_BLOCKED : (uint32_t)WF_FIRE; heat = WF_HEAT_FORCED; }
         if (q == qs) ty = WF_DIRT;                                    // Agent.__init__ digs :111-113
         bool extra = false;
         if (ppm) extra = ty == WF_GRASS && below(key.draw(16u + CELLS + q), 1000000u) < ppm;
@@ -177,7 +178,8 @@ __device__ __forceinline__ void flood(u64 (&R)[4], const u64 (&P)[4])
     }
 }
 
-// A burning cell that dig() retyped to dirt (WF_DIRT_BURNING, allow_dig_toggle only) is impassable, yet the
+// A burning cell that dig() retyped to dirt (WF_DIRT_BURNING, allow_dig_toggle only) or that a river was drawn under
+// (WF_FIRE_BLOCKED, make_rivers only) is impassable, yet the
 // reference's search STARTS from it (the start node's own weight is never charged, pyastar/astar.cpp:41-116):
 // it reaches the border iff one of its 4-neighbours does.  Z = those cells; R = the flooded board.
 template <int W, int H>
@@ -228,8 +230,8 @@ __device__ __forceinline__ void emit_obs(uint8_t *lds, int8_t *obs_e, const uint
     for (int j = 0; j < 4; ++j) {
         const uint32_t t = c[j] & 0xffu;
         lds[oj[j]] = (uint8_t)(c[j] >> 24);                       // agent_pos
-        lds[oj[j] + 1u] = (uint8_t)((2u >> t) & 1u);              // type == fire
-        lds[oj[j] + 2u] = (uint8_t)((7u >> t) & 1u);              // not dirt / water
+        lds[oj[j] + 1u] = (uint8_t)((FIRE_SET >> t) & 1u);        // type == fire (fire, blocked fire)
+        lds[oj[j] + 2u] = (uint8_t)((7u >> t) & 1u);              // not dirt / water / blocked
     }
     if (lane < (uint32_t)G::FULL) {
         const uint4 v = *reinterpret_cast<const uint4 *>(lds + lane * 16u);
@@ -299,7 +301,98 @@ __global__ __launch_bounds__(256) void wf_get_state_wave(const uint32_t *__restr
     }
 }
 
-// World.get_state() (environment.py:399-402): obs[b][x][y][k], any grid shape.
+// World.get_state() (environment.py:399-402): obs[b][x][y][k], any grid shape: an LDS-tiled transpose.
+// obs is planes with [y][x] swapped and 3 bytes per cell instead of 4, so the columns X = b*W + x of the WHOLE batch
+// form one linear sequence of 3H-byte runs.  A workgroup takes TXG consecutive columns (a power of two; they may span
+// environments):
+//   phase 1  lanes run along X: row pieces of the planes come in as coalesced dword loads (a 128-byte line per 32
+//            lanes), each cell becomes the 24-bit triple (agent_pos, type == fire, fire_mobility != inf) and goes to
+//            LDS column-major, tile[col * Hp + y] with Hp odd (lanes of consecutive columns hit different banks);
+//   phase 2  the workgroup's output is ONE contiguous byte range.  A thread packs the triples of 4-5 consecutive cells
+//            of the linear (col, y) sequence into 12 output bytes (three funnel shifts by the range's byte misalignment,
+//            which is workgroup-uniform) and writes them as one 4-byte aligned dwordx3 store; the few head and tail
+//            bytes of the range go out as byte stores.
+// 7 B of traffic per cell (4 read + 3 written).  The kernel it replaces ran one thread per output triple with 64-bit
+// div / mod and read the planes at a stride of 4W bytes: 0.65 TB/s at 1 024 x 256x256.
+__device__ __forceinline__ uint32_t obs_triple(uint32_t c)
+{
+    const uint32_t t = c & 0xffu;
+    return (c >> 24) | (((FIRE_SET >> t) & 1u) << 8) | ((t < (uint32_t)WF_DIRT ? 1u : 0u) << 16);
+}
+
+__global__ __launch_bounds__(256) void wf_get_state_cols(const uint32_t *__restrict__ planes, int8_t *__restrict__ obs,
+                                                        uint32_t ncols, uint32_t H, uint32_t W, uint32_t txg_log2)
+{
+    extern __shared__ uint32_t tile[];                       // [TXG][Hp] triples
+    const uint32_t TXG = 1u << txg_log2, Hp = H | 1u, pad = Hp - H;
+    const uint32_t X0 = blockIdx.x << txg_log2;
+    const uint32_t nX = min(TXG, ncols - X0);
+    // ---- phase 1
+    {
+        const uint32_t lx = threadIdx.x & (TXG - 1u), ly = threadIdx.x >> txg_log2, ystep = 256u >> txg_log2;
+        if (lx < nX) {
+            const uint32_t X = X0 + lx, b = X / W, x = X - b * W;
+            const uint32_t *src = planes + (size_t)b * H * W + x;
+            uint32_t *dst = tile + lx * Hp;
+            for (uint32_t y = ly; y < H; y += ystep * 4u) {          // four independent loads in flight
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t yy = y + (uint32_t)k * ystep;
+                    v[k] = yy < H ? src[(size_t)yy * W] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t yy = y + (uint32_t)k * ystep;
+                    if (yy < H) dst[yy] = obs_triple(v[k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: cells n = col * H + y of the workgroup, linear; LDS address n + (n / H) * pad
+    int8_t *out = obs + (size_t)X0 * H * 3u;
+    const uint32_t len = nX * H * 3u;
+    const uint32_t a0 = min((uint32_t)(-(intptr_t)out) & 3u, len);   // head bytes up to the first aligned dword
+    const uint32_t nchunk = (len - a0) / 12u;                        // 12-byte chunks = 4 cells (+ the shift)
+    const uint32_t ncells = nX * H;
+    // (a chunk's fifth cell may lie past the range: clamped, its bytes are shifted out)
+    auto cell = [&](uint32_t n, uint32_t col) -> uint32_t { return tile[min(n, ncells - 1u) + min(col, nX - 1u) * pad]; };
+    const uint32_t s8 = (a0 % 3u) * 8u, nbase = a0 / 3u;             // chunk i starts at byte 12 i + a0 = cell 4 i + nbase, byte a0 % 3
+    {
+        uint32_t i = threadIdx.x;
+        uint32_t n = 4u * i + nbase;
+        uint32_t col = n / H, y = n - col * H;                       // one division per thread; then incremental
+        const uint32_t dcol = 1024u / H, dy = 1024u - dcol * H;
+        for (; i < nchunk; i += 256u) {
+            uint32_t w[5];
+            uint32_t cc = col, yy = y;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                w[k] = cell(n + (uint32_t)k, cc);
+                if (++yy == H) { yy = 0; ++cc; }
+            }
+            const uint32_t B0 = w[0] | (w[1] << 24), B1 = (w[1] >> 8) | (w[2] << 16), B2 = (w[2] >> 16) | (w[3] << 8), B3 = w[4];
+            struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+            *reinterpret_cast<U3 *>(out + a0 + 12u * i) =
+                U3{ __funnelshift_r(B0, B1, s8), __funnelshift_r(B1, B2, s8), __funnelshift_r(B2, B3, s8) };
+            n += 1024u;
+            col += dcol;
+            y += dy;
+            if (y >= H) { y -= H; ++col; }
+        }
+    }
+    // head and tail bytes (fewer than 16 per workgroup)
+    auto byte_at = [&](uint32_t o) -> int8_t {
+        const uint32_t n = o / 3u, k = o - n * 3u;
+        return (int8_t)(tile[n + (n / H) * pad] >> (8u * k));
+    };
+    const uint32_t tail0 = a0 + 12u * nchunk;
+    if (threadIdx.x < a0) out[threadIdx.x] = byte_at(threadIdx.x);
+    if (tail0 + threadIdx.x < len) out[tail0 + threadIdx.x] = byte_at(tail0 + threadIdx.x);
+}
+
+// fallback for grids too tall for the tile (H >= 16 000): one thread per output triple
 __global__ __launch_bounds__(256) void wf_get_state_kernel(const uint32_t *__restrict__ planes,
                                                           int8_t *__restrict__ obs, int batch, int H, int W)
 {
@@ -308,12 +401,11 @@ __global__ __launch_bounds__(256) void wf_get_state_kernel(const uint32_t *__res
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t b = i / cells, r = i % cells;
         const uint32_t x = (uint32_t)(r / H), y = (uint32_t)(r % H);
-        const uint32_t c = planes[b * cells + (size_t)y * W + x];
-        const uint32_t t = c & 0xffu;
+        const uint32_t tr = obs_triple(planes[b * cells + (size_t)y * W + x]);
         int8_t *o = obs + i * 3;
-        o[0] = (int8_t)(c >> 24);
-        o[1] = (int8_t)(t == WF_FIRE);
-        o[2] = (int8_t)(t < WF_DIRT);                 // fire_mobility != inf
+        o[0] = (int8_t)tr;
+        o[1] = (int8_t)(tr >> 8);
+        o[2] = (int8_t)(tr >> 16);
     }
 }
 
@@ -566,6 +658,18 @@ hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, i
     }
     WF_WAVE_SHAPES(X)
 #undef X
+    // LDS-tiled transpose: TXG columns of Hp = H | 1 triples per workgroup, up to 36 KiB of LDS (4 workgroups per CU)
+    const unsigned long long ncols = (unsigned long long)batch * W;
+    const unsigned Hp = (unsigned)H | 1u;
+    if (Hp <= 16000u && ncols < (1ull << 31) && (unsigned long long)H * 3ull * 64ull < (1ull << 31)) {
+        unsigned lg = 0;
+        while (lg < 6u && (2u << lg) * Hp <= 9216u) ++lg;            // largest TXG = 2^lg <= 64 whose tile fits
+        while (lg > 0u && (ncols >> lg) < 1024ull) --lg;             // small jobs: more, smaller workgroups
+        const unsigned nblk = (unsigned)((ncols + (1ull << lg) - 1) >> lg);
+        hipLaunchKernelGGL(wf_get_state_cols, dim3(nblk), dim3(256), (size_t)(1u << lg) * Hp * 4u, s, planes, obs,
+                           (uint32_t)ncols, (uint32_t)H, (uint32_t)W, (uint32_t)lg);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)batch * H * W;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -74,7 +74,7 @@ __device__ __forceinline__ void stage_obs_row(const ObsTile &ot, uint32_t r, uin
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t t = c[j] & 0xffu;
-        tri[j] = (c[j] >> 24) | (t == (uint32_t)WF_FIRE ? 0x100u : 0u) | (t < (uint32_t)WF_DIRT ? 0x10000u : 0u);
+        tri[j] = (c[j] >> 24) | (((FIRE_SET >> t) & 1u) << 8) | (t < (uint32_t)WF_DIRT ? 0x10000u : 0u);
     }
     uint32_t *p = reinterpret_cast<uint32_t *>(ot.base + (r - ot.row0) * ot.W3 + lane * 12u);
     p[0] = tri[0] | (tri[1] << 24);
@@ -114,6 +114,7 @@ struct Pack {
     uint32_t row_off;        // this lane's segment * 16: its row at sweep position r is r + row_off
     uint32_t ql;             // this lane's quad within the row
     bool col_ok;             // the quad exists (ql < W / 4)
+    bool rivers;             // the context was created with make_rivers: WF_FIRE_BLOCKED cells can exist
     u64 XL;                  // lane of the quad holding x == W-1, in every segment
 };
 
@@ -149,6 +150,11 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
             if (j == 3) A.ign_xl |= IGN;                                    // cells with x == W-1 (lane LW-1)
             FIRE[j] = Sc[j] | IGN;
             GR[j] = G & ~IGN;
+        }
+        // make_rivers only (kernel-uniform branch): a blocked fire cell (13) burns out to blocked burnt (6), not 14
+        if (pk.rivers) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] &= ~((c[j] << 2) & 8u);
         }
         // set_fire_to :245-246: first / last row of the grid are border rows
         if constexpr (P == 1) {
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     pk.row_off = (P == 1 ? 0u : lane / LWP) * (uint32_t)TR;
     pk.ql = P == 1 ? lane : lane % LWP;
     pk.col_ok = pk.ql < LW;
+    pk.rivers = (a.hot_flags & WF_HOT_RIVERS) != 0;
     pk.XL = Pack<P>::X0 << (LW - 1u);
     const uint32_t lane_cell0 = pk.row_off * LW + pk.ql;         // this lane's quad index at sweep position 0 (+ r * LW)
     const uint32_t ign = (uint32_t)a.ignite_count;
@@ -465,14 +472,15 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
         }
         __syncthreads();
         u64 *out = a.reach + (size_t)e * words;
-        if (a.hot_flags & WF_HOT_DIG_TOGGLE) {
-            // Burning dirt (WF_DIRT_BURNING) is impassable, yet the reference's search starts FROM it: it reaches the
-            // border iff one of its 4-neighbours does.  One row per wave iteration: re-read the row, add those cells.
+        if (a.hot_flags & WF_HOT_RARE) {
+            // Burning dirt (WF_DIRT_BURNING) and a fire cell over a river (WF_FIRE_BLOCKED) are impassable, yet the
+            // reference's search starts FROM them: such a cell reaches the border iff one of its 4-neighbours does.
+            // One row per wave iteration: re-read the row, add those cells.
             for (uint32_t r = wv; r < H; r += 4u) {
                 uint4 c = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
                 if (lane < LW) c = src[r * LW];
-                const u64 Z[4] = { __ballot((c.x & 0xffu) == WF_DIRT_BURNING), __ballot((c.y & 0xffu) == WF_DIRT_BURNING),
-                                   __ballot((c.z & 0xffu) == WF_DIRT_BURNING), __ballot((c.w & 0xffu) == WF_DIRT_BURNING) };
+                const u64 Z[4] = { __ballot(blocked_burning(c.x)), __ballot(blocked_burning(c.y)),
+                                   __ballot(blocked_burning(c.z)), __ballot(blocked_burning(c.w)) };
                 if (lane < 4u) {
                     const uint32_t j = lane, k = r * 4u + j;
                     u64 nb = (r > 0 ? reach[k - 4] : 0ull) | (r + 1 < H ? reach[k + 4] : 0ull);

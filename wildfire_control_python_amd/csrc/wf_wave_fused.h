@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 const uint32_t td = type_of(tp, qd);
                 const uint32_t tcur = type_of(tp, qa);
                 const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u);         // :146 traversable
-                const uint32_t dfire = moved & (2u >> td);                             // destination burning
+                constexpr uint32_t ONFIRE = RARE ? FIRE_SET : 2u;                      // is_burning(): type fire (RARE: blocked fire too)
+                const uint32_t dfire = moved & (ONFIRE >> td);                         // destination burning
                 uint32_t dug = moved & (fl >> 2) & (DIG_SET >> td) & 1u;               // digging, not burning, not dirt yet (:151-152, :125-133)
                 uint32_t dugtype = (uint32_t)WF_DIRT;
                 fl = (fl & ~(ism << 1)) | (moved << 1) | (dfire << 3);                 // :142, :148-149, :154-155
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         fl ^= WF_F_DIGGING;
                         // dig() under the agent: a BURNING cell too, which stays in burning_cells under its
                         // new type (WF_DIRT_BURNING)
-                        dug = (fl >> 2) & ((DIG_SET | 2u) >> tcur) & 1u;
-                        dugtype = tcur == (uint32_t)WF_FIRE ? (uint32_t)WF_DIRT_BURNING : dugtype;
+                        dug = (fl >> 2) & ((DIG_SET | ONFIRE) >> tcur) & 1u;
+                        dugtype = ((ONFIRE >> tcur) & 1u) ? (uint32_t)WF_DIRT_BURNING : dugtype;
                         qd = qa;
                     }
                 }
@@ -212,16 +213,16 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 const bool do_update = FUSED ? (bool)((a.update_mask >> st) & 1ull) : (bool)(a.update_mask & 1ull);
                 if (do_update) {
                     // :87 drop dead agents (Agent.is_dead environment.py:116-120)
-                    const uint32_t dies = fl & ((fl >> 3) | (2u >> ta)) & 1u;          // alive & (dead | on fire)
+                    const uint32_t dies = fl & ((fl >> 3) | (ONFIRE >> ta)) & 1u;      // alive & (dead | on fire)
                     fl &= ~(dies * (uint32_t)(WF_F_ALIVE | WF_F_VISIBLE));
 
                     u64 STILL[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // reduce_fuel (:297-307): a fire cell whose fuel-1 > 0 keeps burning
-                        const uint32_t key = ((t[j] & 3u) << 8) + u[j];               // burning: fire (1) or burning dirt (5)
+                        const uint32_t key = ((t[j] & 3u) << 8) + u[j];               // burning: fire (1), burning dirt (5), blocked fire (13)
                         STILL[j] = __ballot((key - 0x102u) < 0x7Eu);                   // burning && 2<=fuel<=127
-                        const uint32_t isfire = (0x22u >> t[j]) & 1u;
+                        const uint32_t isfire = ((RARE ? 0x2022u : 0x22u) >> t[j]) & 1u;
                         u[j] = (u[j] - isfire) & 0xffu;
                         t[j] += isfire;                                                // fire -> burnt ...
                     }
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         constexpr int j = decltype(J)::value;
                         using C = CM<W, H, j>;
                         t[j] -= lanebit(STILL[j]) ? 1u : 0u;                           // ... unless still burning
+                        if constexpr (RARE) t[j] &= ~((t[j] << 2) & 8u);               // burnt-out blocked fire: 14 -> 6 (blocked burnt)
                         // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294): count the
                         // still-burning 4-neighbours.  Vertical: pure mask shifts.  Horizontal: the
                         // row-wrap guard is the per-lane constant, not a 64-bit scalar mask.
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         const uint32_t rot = ((ring << 1) | (ring >> 7)) & 0xffu;
                         const uint32_t runs = (uint32_t)__popc(ring & ~rot);
                         recompute |= dug & (onb | (runs >> 1) | (runs >> 2));
-                        if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE))      // digging next to burning dirt may cut its last link (see wf_step_group)
-                            recompute |= dug & ((uint32_t)__ballot(ty == (uint32_t)WF_DIRT_BURNING && !rout && lane < 8u && !(lane & 1u)) ? 1u : 0u);
+                        if constexpr (RARE)      // digging next to burning dirt / a blocked fire cell may cut its last link (see wf_step_group)
+                            recompute |= dug & ((uint32_t)__ballot(blocked_burning(ty) && !rout && lane < 8u && !(lane & 1u)) ? 1u : 0u);
                     }
                     if (rfl(recompute)) {
                         u64 PASS[4];
@@ -294,10 +296,10 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                         for (int j = 0; j < 4; ++j) PASS[j] = ~__ballot(t[j] >= WF_DIRT);
                         static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                         flood<W, H>(RB, PASS);
-                        if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
+                        if constexpr (RARE) {
                             u64 Z[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) Z[j] = __ballot(t[j] == (uint32_t)WF_DIRT_BURNING);
+                            for (int j = 0; j < 4; ++j) Z[j] = __ballot(blocked_burning(t[j]));
                             add_blocked_burning<W, H>(RB, Z);
                         }
                         fl = (fl | WF_F_REACH_VALID) & ~(uint32_t)WF_F_REACH_ROWS;      // the rows-layout board is stale now

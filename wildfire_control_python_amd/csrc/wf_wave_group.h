@@ -74,7 +74,7 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
             const uint32_t nq = off ? 0u : qx + (uint32_t)(DY[r] * W + DX[r]);
             const uint32_t ty = *reinterpret_cast<const uint8_t *>(planes_b + (pbase + nq * 4u));
             ring |= ((off ^ 1u) & (ty < (uint32_t)WF_DIRT ? 1u : 0u)) << r;
-            if constexpr (RARE) zring |= ((off ^ 1u) & (ty == (uint32_t)WF_DIRT_BURNING ? 1u : 0u)) << r;
+            if constexpr (RARE) zring |= ((off ^ 1u) & (blocked_burning(ty) ? 1u : 0u)) << r;
         }
         // which 4-neighbours (ring bits 0,2,4,6 = N,E,S,W) are border cells themselves
         const uint32_t ex = x0 | xl, ey = y0 | yl;
@@ -82,7 +82,8 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
                  ((ex | (yd == (uint32_t)(H - 2) ? 1u : 0u)) << 4) | ((ey | (xd == 1u ? 1u : 0u)) << 6);
     }
     const uint32_t moved = inb & min(td ^ (uint32_t)WF_WATER, 1u) & running;           // :146 traversable
-    const uint32_t dfire = moved & (2u >> td);                                         // destination burning
+    constexpr uint32_t ONFIRE = RARE ? FIRE_SET : 2u;                                  // is_burning(): type fire (RARE: blocked fire too)
+    const uint32_t dfire = moved & (ONFIRE >> td);                                     // destination burning
     uint32_t dug = moved & (fl >> 2) & (DIG_SET >> td) & 1u;                           // :151-152, :125-133 (not dirt, not burning)
     uint32_t dugtype = (uint32_t)WF_DIRT;
     const uint32_t vis_before = (fl >> 1) & 1u & running;
@@ -95,14 +96,14 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
         fl ^= tg << 2;
         // dig() under the agent: any cell that is not dirt - a BURNING one too, which stays in burning_cells
         // under its new type (WF_DIRT_BURNING)
-        const uint32_t dugt = (fl >> 2) & ((DIG_SET | 2u) >> tcur) & 1u;
+        const uint32_t dugt = (fl >> 2) & ((DIG_SET | ONFIRE) >> tcur) & 1u;
         dug = tg ? dugt : dug;
         qd = tg ? qa : qd;
-        if constexpr (RARE) dugtype = (tg & (2u >> tcur) & 1u) ? (uint32_t)WF_DIRT_BURNING : dugtype;
+        if constexpr (RARE) dugtype = (tg & (ONFIRE >> tcur) & 1u) ? (uint32_t)WF_DIRT_BURNING : dugtype;
     }
     ta += dug * ((uint32_t)WF_DIRT - ta);
     if (do_update) {   // forest_fire.py:87 drop dead agents (Agent.is_dead environment.py:116-120)
-        const uint32_t dies = fl & ((fl >> 3) | (2u >> ta)) & 1u & running;
+        const uint32_t dies = fl & ((fl >> 3) | (ONFIRE >> ta)) & 1u & running;
         fl &= ~(dies * (uint32_t)(WF_F_ALIVE | WF_F_VISIBLE));
     }
     const uint32_t vis_after = (fl >> 1) & 1u;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     const u64 F = __ballot(burning<RARE>(c[j]));                         // burning: fire or burning dirt
                     STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                     // fuel -= 1 and fire -> burnt, unless still burning (type stays fire)
-                    const uint32_t d = lanebit(STILL[j]) ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
+                    const uint32_t d = lanebit(STILL[j]) ? (K_FIRE_STEP - 1u) : burn_out_step<RARE>(c[j]);
                     c[j] = pk_add_u16(c[j], lanebit(F) ? d : 0u);
                 }
                 uint32_t ign_bits = 0;
@@ -359,10 +360,10 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     for (int j = 0; j < 4; ++j) PASS[j] = __ballot((c[j] & 0xffu) < (uint32_t)WF_DIRT);
                     static_for<4>([&](auto J) { constexpr int j = decltype(J)::value; RB[j] = CM<W, H, j>::BORDER & PASS[j]; });
                     flood<W, H>(RB, PASS);
-                    if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
+                    if constexpr (RARE) {
                         u64 Z[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Z[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_DIRT_BURNING);
+                        for (int j = 0; j < 4; ++j) Z[j] = __ballot(blocked_burning(c[j]));
                         add_blocked_burning<W, H>(RB, Z);
                     }
                     if (lane == 0) {

@@ -198,7 +198,8 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
         int32_t fuel = fuel_lo;
         if (span > 1u) fuel += (int32_t)below(key.draw(16u + q), span);
         uint32_t ty = ((water >> j) & 1u) ? (uint32_t)WF_WATER : (uint32_t)WF_GRASS, heat = 0;
-        if (q == qc) { ty = WF_FIRE; heat = WF_HEAT_FORCED; }         // set_fire_to :233-246
+        // set_fire_to :233-246; under a river the cell keeps its infinite fire mobility (:85)
+        if (q == qc) { ty = ty == (uint32_t)WF_WATER ? (uint32_t)WF_FIRE_BLOCKED : (uint32_t)WF_FIRE; heat = WF_HEAT_FORCED; }
         if (q == qs) ty = WF_DIRT;                                    // Agent.__init__ digs :111-113
         bool extra = false;
         if (ppm) extra = ty == WF_GRASS && below(key.draw(16u + CELLS + q), 1000000u) < ppm;
@@ -436,7 +437,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                         STILL[j] = F & __ballot((int32_t)(int8_t)(c[j] >> 8) > 1);     // fuel - 1 > 0
                         const bool st = lanebit(STILL[j]);
                         sv[j] = st ? 1u : 0u;
-                        const uint32_t d = st ? (K_FIRE_STEP - 1u) : K_FIRE_STEP;
+                        const uint32_t d = st ? (K_FIRE_STEP - 1u) : burn_out_step<RARE>(c[j]);
                         const uint32_t dd = lanebit(F) ? d : 0u;
                         c[j] = pk_add_u16(c[j], dd);
                         chg |= dd;
@@ -503,11 +504,11 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                     }
 #endif
                     flood_rows<W, H, S>(NB, PASS);
-                    if (RARE && (a.hot_flags & WF_HOT_DIG_TOGGLE)) {
-                        // burning dirt reaches the border through its 4-neighbours (see add_blocked_burning)
+                    if constexpr (RARE) {
+                        // burning dirt / a blocked fire cell reaches the border through its 4-neighbours (see add_blocked_burning)
                         u64 ZB[CPL], ADD[CPL];
 #pragma unroll
-                        for (int j = 0; j < CPL; ++j) ZB[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_DIRT_BURNING);
+                        for (int j = 0; j < CPL; ++j) ZB[j] = __ballot(blocked_burning(c[j]));
                         static_for<CPL>([&](auto J) {
                             constexpr int j = decltype(J)::value;
                             ADD[j] = ((NB[j] << S) | (NB[j] >> S) | rg_lf<W, H, S, j>(NB) | rg_rt<W, H, S, j>(NB)) & ZB[j];
@@ -569,8 +570,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                     for (int j = 0; j < CPL; ++j) {
                         const uint32_t t = c[j] & 0xffu, o = ob + (uint32_t)(j * H * 3);
                         obs_lds[o] = (uint8_t)(c[j] >> 24);                       // agent_pos
-                        obs_lds[o + 1u] = (uint8_t)((2u >> t) & 1u);              // type == fire
-                        obs_lds[o + 2u] = (uint8_t)((7u >> t) & 1u);              // not dirt / water
+                        obs_lds[o + 1u] = (uint8_t)((FIRE_SET >> t) & 1u);        // type == fire (fire, blocked fire)
+                        obs_lds[o + 2u] = (uint8_t)((7u >> t) & 1u);              // not dirt / water / blocked
                     }
                     const uint32_t nenv = min((uint32_t)EPW, ng - kb);
                     const uint32_t nbytes = nenv * OBS_BYTES;                     // multiple of 4

@@ -22,8 +22,9 @@ from . import _native as N
 from .batched import BatchedForestFire, encode_action
 from .utility import get_name, grass, layer, temp_from_count, type2ascii, type2gray
 
-# look-up tables indexed by the boundary's type code (0..6; 5 = burning dirt, 6 = blocked burnt: include/wildfire.h)
-_REF_TYPE = np.array([0, 1, 2, 3, 4, 3, 2], dtype=np.int64)    # the type the reference's World.env would hold
+# look-up tables indexed by the boundary's type code (5 = burning dirt, 6 = blocked burnt, 13 = blocked fire:
+# include/wildfire.h; 7..12 are not used)
+_REF_TYPE = np.array([0, 1, 2, 3, 4, 3, 2, 0, 0, 0, 0, 0, 0, 1], dtype=np.int64)    # the type the reference's World.env would hold
 _ASCII = np.array([type2ascii[int(t)] for t in _REF_TYPE])
 _GRAY = np.array([type2gray[int(t)] for t in _REF_TYPE])
 
@@ -96,7 +97,7 @@ class World:
     def burning_cells(self):
         """World.burning_cells (environment.py:202): the set of (x, y) of every cell that burns."""
         if self._burning_cells is None:
-            ys, xs = np.nonzero((self._planes[:, :, N.P_TYPE] & 3) == 1)      # fire, or dirt dug under a fire (code 5)
+            ys, xs = np.nonzero((self._planes[:, :, N.P_TYPE] & 3) == 1)      # fire (1, 13), or dirt dug under a fire (5)
             self._burning_cells = set(zip(xs.tolist(), ys.tolist()))
         return self._burning_cells
 
@@ -141,21 +142,24 @@ class World:
         out[:, :, layer["threshold"]] = grass["threshold"]
         out[:, :, layer["agent_pos"]] = p[:, :, N.P_AGENT].T
         out[:, :, layer["fire_mobility"]] = np.where(code >= N.DIRT, np.inf, 1.0)
-        out[:, :, layer["agent_mobility"]] = np.where(code == N.WATER, np.inf, 1.0)
+        # (the river cell under the fire keeps the agent_mobility reset_map gave it, environment.py:87)
+        out[:, :, layer["agent_mobility"]] = np.where((code == N.WATER) | (code == N.FIRE_BLOCKED), np.inf, 1.0)
         out.setflags(write=False)
         return out
 
     def _temp(self):
         """float64 (H, W): the temp layer.  Wind vector (0,0): the running sum of equal addends the heat plane counts.
         Wind with a direction: the sum of the counted per-direction addends of a grass cell; threshold + 1 where
-        set_fire_to forced it (environment.py:236-237); nan for a cell that accumulated heat ignited (the build
-        keeps no temperature for a cell that can never take heat again)."""
+        set_fire_to forced it (environment.py:236-237); threshold + 0.5 - a finite stand-in above the threshold - for a
+        cell that accumulated heat ignited (the reference keeps the sum that crossed the threshold; the build keeps no
+        temperature for a cell that can never take heat again, and the temperature of a burning or burnt cell is
+        never read by the rule)."""
         heat = self._planes[:, :, N.P_HEAT]
         if self._counts is None:
             return np.vectorize(lambda n: temp_from_count(n, self.wind_speed))(heat)
         t = (self._counts.astype(np.float64) * self._addends).sum(axis=-1)
         t[heat == N.HEAT_FORCED] = grass["threshold"] + 1
-        t[heat == N.HEAT_IGNITED] = np.nan
+        t[heat == N.HEAT_IGNITED] = grass["threshold"] + 0.5
         return t
 
     def inbounds(self, x, y):                                   # environment.py:225-226
@@ -166,7 +170,7 @@ class World:
 
     def is_burning(self, cell):                                 # environment.py:249-251
         x, y = cell
-        return self._planes[y, x, N.P_TYPE] == N.FIRE
+        return self._planes[y, x, N.P_TYPE] in (N.FIRE, N.FIRE_BLOCKED)
 
     def is_burnable(self, cell):                                # environment.py:254-257
         x, y = cell
@@ -175,7 +179,7 @@ class World:
     def get_state(self):                                        # environment.py:399-402
         p = self._planes
         t = p[:, :, N.P_TYPE].T
-        return np.dstack((p[:, :, N.P_AGENT].T.astype(np.float64), t == N.FIRE, t < N.DIRT))
+        return np.dstack((p[:, :, N.P_AGENT].T.astype(np.float64), (t == N.FIRE) | (t == N.FIRE_BLOCKED), t < N.DIRT))
 
     def get_reward(self):
         """Reward of the last step (the reference recomputes it with side effects on
@@ -227,8 +231,15 @@ class World:
 
 class ForestFire:
     def __init__(self, device=0, metadata=None, size=None):
+        """With neither `metadata` nor `size` the object works on the package's module-global METADATA dict
+        (constants.METADATA), exactly like the reference (forest_fire.py:20; constants.py:30-57): edit that dict before
+        constructing, and - the reference's global-state quirk - every such object of the process shares the a_speed
+        counter step() mutates (forest_fire.py:40-43).  With arguments it owns a private copy."""
+        from .constants import METADATA as shared
+        if metadata is None and size is None:
+            metadata = shared
         self._b = BatchedForestFire(1, size=size, device=device, metadata=metadata)
-        self.METADATA = self._b.METADATA                        # forest_fire.py:21 (own copy here)
+        self.METADATA = self._b.METADATA                        # forest_fire.py:21
         self.DEBUG = self.METADATA["debug"]
         self.layer = layer
         self.get_name = get_name
