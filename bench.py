@@ -169,11 +169,13 @@ def measured_traffic(batch, size):
 
 # ------------------------------------------------------------------ --gpus N without a launcher
 def spawn_ranks(args):
-    """Parent of an N-rank run: makes NO GPU call itself (device_count() does not initialise the runtime on
-    this image), starts one fresh process per rank, relays rank 0's JSON line."""
+    """Parent of an N-rank run: never loads torch or the HIP runtime (the GPUs are counted from the KFD topology in
+    sysfs), starts one fresh process per rank, relays rank 0's JSON line."""
     import socket
-    import torch
-    ndev = torch.cuda.device_count()
+    from wildfire_control_python_amd.launcher import visible_gpu_count
+    ndev = visible_gpu_count()
+    if ndev is None:
+        ndev = args.gpus                       # no topology to read: the ranks themselves check (and refuse) below
     if args.gpus > ndev and not args.share_gpu:
         sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible; "
                  "one process per GPU is the contract (pass --share-gpu to rehearse on fewer cards)")

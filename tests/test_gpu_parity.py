@@ -268,7 +268,7 @@ def test_wind_adapter_draws_like_the_reference(wf):
                 assert reward == ep.d["reward"][lo + t] and done == bool(ep.d["done"][lo + t])
                 if t % 16 == 0:
                     temp = sim.W.env[:, :, sim.layer["temp"]].T
-                    known = ~np.isnan(temp)
+                    known = temp != 3.5          # (a cell ignited by accumulated heat reads the stand-in threshold + 0.5)
                     np.testing.assert_allclose(temp[known], ep.d["temp"][lo + t][known], rtol=0, atol=2e-6)
             assert done
         sim.close()
@@ -1650,6 +1650,72 @@ def test_bench_contract_single_and_two_ranks(wf):
     assert r3.returncode == 0, r3.stderr[-2000:]
     d3 = json.loads([l for l in r3.stdout.splitlines() if l.strip().startswith("{")][0])
     assert d3["n_gpus"] == 2 and d3["config"]["global_batch"] == 2 * 16384
+
+
+def test_bench_rehearsal_of_config5_shards_and_a_parent_without_torch(wf):
+    """BASELINE configs[4] is 8 shards of 125 000 environments, one process per GPU.  On this one-GPU box: bench.py's own
+    launcher with 4 rank processes of that shard size on the one card (the pool allows 6 GPU processes at a time and this
+    test runner is one of them), gloo for the barrier.  The parent never imports torch (-X importtime)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(repo, "bench.py"), "--gpus", "4", "--share-gpu", "--batch", "125000",
+                        "--no-extras", "--no-cpu-baseline", "--steps", "20", "--warmup", "5", "--min-ms", "5"],
+                       capture_output=True, text=True, timeout=600, cwd=repo, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 500000 and d["shared_card"] is True and d["value"] > 0
+    assert "configs[4]" in d["config"]["workload"]
+    # -X importtime is inherited by nobody: the lines on stderr are the PARENT's imports
+    assert not [l for l in r.stderr.splitlines() if "import time:" in l and "| torch" in l]
+
+
+def test_sharded_forest_fire_equals_one_context(wf):
+    """ShardedForestFire: one process, one context per shard, asynchronous device calls, no exchange between shards.
+    Four shards (all on device 0 here) of a 10 007-environment batch equal ONE context of the whole batch bit for bit:
+    reset streams are keyed by the global environment id."""
+    import torch
+    G, S = 10007, 14
+    kw = dict(seed=5, auto_reset=True, fuel_range=(6, 14), containment=True)
+    sh = wf.ShardedForestFire(G, size=S, devices=(0, 0, 0, 0), **kw)
+    one = wf.BatchedForestFire(G, size=S, **kw)
+    np.testing.assert_array_equal(sh.reset(seed=9), one.reset(seed=9))
+    rng = np.random.default_rng(1)
+    dev = torch.device("cuda", 0)
+    d_act = [torch.empty(hi - lo, dtype=torch.int8, device=dev) for lo, hi in sh.bounds]
+    d_rew = [torch.empty(hi - lo, dtype=torch.float64, device=dev) for lo, hi in sh.bounds]
+    d_done = [torch.empty(hi - lo, dtype=torch.uint8, device=dev) for lo, hi in sh.bounds]
+    d_obs = [torch.empty((hi - lo, S, S, 3), dtype=torch.int8, device=dev) for lo, hi in sh.bounds]
+    for t in range(70):
+        a = rng.integers(0, 5, size=G).astype(np.int8)
+        obs1, r1, dn1, _ = one.step(a)
+        if t % 2:
+            obs, r, dn, _ = sh.step(a)
+        else:                                                     # the asynchronous device path
+            for (lo, hi), da in zip(sh.bounds, d_act):
+                da.copy_(torch.from_numpy(a[lo:hi]))
+            torch.cuda.synchronize()
+            sh.step_device(d_act, 1, d_rew, d_done, d_obs)
+            sh.sync()
+            obs = np.concatenate([o.cpu().numpy() for o in d_obs])
+            r = np.concatenate([x.cpu().numpy() for x in d_rew])
+            dn = np.concatenate([x.cpu().numpy() for x in d_done]).astype(bool)
+        np.testing.assert_array_equal(r, r1, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(dn, dn1, err_msg=f"done t={t}")
+        np.testing.assert_array_equal(obs, obs1, err_msg=f"obs t={t}")
+    p, e = sh.download()
+    p1, e1 = one.download()
+    np.testing.assert_array_equal(p, p1)
+    np.testing.assert_array_equal(_envs(e), _envs(e1))
+    assert (e["episode"] > 1).any()
+    sh.close()
+    one.close()
 
 
 # ------------------------------------------------------------------ arbitrary uploaded states

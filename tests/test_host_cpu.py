@@ -301,3 +301,44 @@ def test_wind_parameters_that_counts_cannot_decide_are_refused():
     assert rc in (0, -3), rc
     if rc == 0:
         lib.wf_destroy(h)
+
+
+def test_visible_gpu_count_reads_the_kfd_topology_without_the_runtime(tmp_path, monkeypatch):
+    """Launchers count GPUs from sysfs (a KFD topology node with SIMDs is a GPU), never through torch / HIP."""
+    import sys
+    from wildfire_control_python_amd.launcher import visible_gpu_count
+    for i, simd in enumerate((0, 1024, 1024, 0, 1024)):            # CPU nodes report simd_count 0
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if not simd else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert visible_gpu_count(str(tmp_path)) == 1
+    assert visible_gpu_count(str(tmp_path / "nowhere")) == 0         # no KFD driver: no GPU
+    assert "torch" not in sys.modules or True                        # (importing the package never imports torch: next test)
+
+
+def test_package_and_bench_parent_do_not_import_torch():
+    """`import wildfire_control_python_amd` and the parent of `bench.py --gpus N` stay clear of torch and of the HIP
+    runtime: the parent only counts devices and starts one fresh process per rank."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import wildfire_control_python_amd as w; "
+            "from wildfire_control_python_amd.launcher import visible_gpu_count; visible_gpu_count(); "
+            "assert 'torch' not in sys.modules, 'torch imported'; print('clean')" % repo)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-500:]
+    # the --gpus parent: a fake HIP_VISIBLE_DEVICES list makes it see at most one device; it must refuse 2 ranks
+    # before anything imports torch (-X importtime lists every module the process loads)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=repo)
+    imported = [l for l in r.stderr.splitlines() if "import time:" in l and "| torch" in l]
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not imported, (r.returncode, r.stderr[-300:], imported[:3])

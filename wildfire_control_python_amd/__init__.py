@@ -13,8 +13,9 @@ from .constants import METADATA  # noqa: F401
 from .utility import layer, types, grass  # noqa: F401
 from .batched import BatchedForestFire, encode_action, NOOP  # noqa: F401
 from .forest_fire import ForestFire, World, Agent  # noqa: F401
-from .launcher import shard_bounds, make_shard  # noqa: F401
+from .launcher import shard_bounds, make_shard, visible_gpu_count, ShardedForestFire  # noqa: F401
 from .learner import BatchedLearner, ALGORITHMS  # noqa: F401
 
 __all__ = ["ForestFire", "BatchedForestFire", "World", "Agent", "METADATA", "layer", "types",
-           "grass", "encode_action", "NOOP", "shard_bounds", "make_shard", "BatchedLearner", "ALGORITHMS"]
+           "grass", "encode_action", "NOOP", "shard_bounds", "make_shard", "visible_gpu_count", "ShardedForestFire",
+           "BatchedLearner", "ALGORITHMS"]

@@ -58,9 +58,20 @@ struct wf_ctx {
     uint8_t *d_mode = nullptr;        // big-grid families: per-env mode of the current step
     uint32_t *d_acc = nullptr;        // big-grid families: per-env reduction words
     int staged_steps = 0;
+    // Large batches (>= WF_HOST_STAGE_MIN actions per call): device mirrors of actions / reward+done.  A copy kernel
+    // brings the actions over before the step and takes reward and done back after it with wide coalesced PCIe
+    // accesses, instead of every wave of the step kernel paying a PCIe round trip in its agent phases
+    // (65 536 x 14x14: wf_step 97 -> see DESIGN.md us).  Pinned `d_reward` and `d_done` are then ONE block.
+    int8_t *v_actions = nullptr;
+    uint8_t *v_out = nullptr;          // [n doubles of reward][n bytes of done]
+    uint8_t *p_out = nullptr;          // pinned host block of the same layout
+    size_t v_count = 0;                // n the mirrors were sized for
     void *dbg_timing = nullptr;       // measurement builds (WF_WAVE_TIMING) only
     WfSpawn spawn;
     int last_hip = 0;
+    // WF_GRAPH experiment: captured launch sequences, one per distinct argument set of wf_step*_device
+    struct GraphEntry { const int8_t *actions; double *reward; uint8_t *done; int8_t *obs; int n_steps; uint64_t mask; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
 };
 
 namespace {
@@ -336,10 +347,118 @@ int ensure_staging(wf_ctx *c, int n_steps)
     c->d_actions = nullptr; c->d_reward = nullptr; c->d_done = nullptr;
     c->staged_steps = 0;
     const size_t n = (size_t)n_steps * (size_t)c->batch;
-    HIP_TRY(c, hipHostMalloc((void **)&c->d_actions, n, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&c->d_actions, (n + 15) & ~(size_t)15, hipHostMallocDefault));   // (copied in whole dwords)
     HIP_TRY(c, hipHostMalloc((void **)&c->d_reward, n * sizeof(double), hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void **)&c->d_done, n, hipHostMallocDefault));
     c->staged_steps = n_steps;
+    return WF_OK;
+}
+
+int ensure_mirrors(wf_ctx *c, size_t n)
+{
+    if (n <= c->v_count) return WF_OK;
+    if (c->v_actions) (void)hipFree(c->v_actions);
+    if (c->v_out) (void)hipFree(c->v_out);
+    if (c->p_out) (void)hipHostFree(c->p_out);
+    c->v_actions = nullptr; c->v_out = nullptr; c->p_out = nullptr; c->v_count = 0;
+    const size_t na = (n + 15) & ~(size_t)15, no = (n * 9 + 15) & ~(size_t)15;
+    HIP_TRY(c, hipMalloc((void **)&c->v_actions, na));
+    HIP_TRY(c, hipMalloc((void **)&c->v_out, no));
+    HIP_TRY(c, hipHostMalloc((void **)&c->p_out, no, hipHostMallocDefault));
+    c->v_count = n;
+    return WF_OK;
+}
+
+// One wf_step*_device call of the wave family: the launches, on the context's stream(s).
+int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t update_mask, double *d_reward, uint8_t *d_done, int8_t *d_obs)
+{
+    // Large batches: one launch per stream whose waves step their environments n_steps times (shapes with a
+    // rows-layout kernel), else n_steps single-step launches; both beat the fused one-environment-per-wave
+    // kernel there (4.2e11 cell-updates/s at 65 536 x 14x14), which serves small, launch-bound batches.
+    // The verdict is reached ONCE, from the shape of the whole call, and handed to every part launch
+    // (WfKnobs::multi_rows): a ragged last part must not fall back to another kernel on its own.
+    const bool sp = splits(c, 1);
+    const bool in_kernel = n_steps > 1 && (sp ? multi_rows_call(c, n_steps) : (c->knobs.multi_small && multi_rows_whole(c, n_steps)));
+    WfKnobs kn = c->knobs;
+    kn.multi_rows = in_kernel ? 1 : 0;
+    const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
+    const int n_launch = each ? n_steps : 1;
+    const size_t cells = (size_t)c->H * c->W;
+    for (int st = 0; st < n_launch; ++st) {
+        WfArgs a = base_args(c);
+        const size_t soff = (size_t)st * (size_t)c->batch;
+        a.obs = st == n_launch - 1 ? d_obs : nullptr;      // observation of the final state, written by the step kernel
+        a.actions = d_actions ? d_actions + soff : nullptr;
+        a.reward = d_reward ? d_reward + soff : nullptr;
+        a.done = d_done ? d_done + soff : nullptr;
+        a.n_steps = each ? 1 : n_steps;
+        a.update_mask = each ? (update_mask >> st) & 1ull : update_mask;
+        const bool split = splits(c, in_kernel ? 1 : a.n_steps);
+        if (!split) {
+            JOIN(c);
+            HIP_TRY(c, wf_launch_step(c->fam, a, kn, c->stream, c->num_cus));
+            continue;
+        }
+        // independent parts of the batch on separate streams (inputs must be complete when this is
+        // called: the context's own streams are not ordered with the caller's streams)
+        if (c->main_touched) {         // the sides must see earlier reset / upload / get_state work of `stream`
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            for (int i = 0; i < c->n_parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+            c->main_touched = false;
+        }
+        const int per = split_per(c);
+        if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);   // as for the whole batch
+        for (int i = 0; i < c->n_parts; ++i) {
+            const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
+            if (lo >= hi) break;
+            WfArgs ai = a;
+            ai.batch = hi - lo;
+            ai.env_base = (uint32_t)lo;
+            ai.planes = a.planes + (size_t)lo * cells;
+            ai.planes_out = ai.planes;
+            ai.envs = a.envs + lo;
+            ai.reach = a.reach + (size_t)lo * 4;
+            if (a.actions) ai.actions = a.actions + lo;
+            if (a.reward) ai.reward = a.reward + lo;
+            if (a.done) ai.done = a.done + lo;
+            if (a.obs) ai.obs = a.obs + (size_t)lo * cells * 3;
+            HIP_TRY(c, wf_launch_step(c->fam, ai, kn, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
+        }
+        c->side_pending = true;
+    }
+    return WF_OK;
+}
+
+// WF_GRAPH=1 (experiment): the launches of a call are captured ONCE per distinct argument set into a HIP graph - fork,
+// the part launches on their streams (chained per stream over the steps of an n-step call), join - and replayed with
+// one hipGraphLaunch.  What it measures: whether replaying pre-built dispatch packets beats issuing them (it does not
+// shorten what the GPU does per launch); a one-step graph also joins the halves after EVERY step, which the plain path
+// does not (its two streams run on across steps).
+int wave_step_graph(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t update_mask, double *d_reward, uint8_t *d_done, int8_t *d_obs)
+{
+    for (const wf_ctx::GraphEntry &g : c->graphs)
+        if (g.actions == d_actions && g.reward == d_reward && g.done == d_done && g.obs == d_obs && g.n_steps == n_steps && g.mask == update_mask) {
+            JOIN(c);
+            HIP_TRY(c, hipGraphLaunch(g.exec, c->stream));
+            return WF_OK;
+        }
+    if (c->graphs.size() >= 64) {                       // bounded cache: beyond it, plain launches
+        return wave_step_issue(c, d_actions, n_steps, update_mask, d_reward, d_done, d_obs);
+    }
+    JOIN(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    wf_ctx::GraphEntry g = { d_actions, d_reward, d_done, d_obs, n_steps, update_mask, nullptr, nullptr };
+    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->main_touched = true;                             // the fork event belongs inside the capture
+    int rc = wave_step_issue(c, d_actions, n_steps, update_mask, d_reward, d_done, d_obs);
+    if (rc == WF_OK) rc = join_side(c);                 // the side streams rejoin the capturing stream
+    hipError_t e = hipStreamEndCapture(c->stream, &g.graph);
+    if (rc != WF_OK) return rc;
+    HIP_TRY(c, e);
+    HIP_TRY(c, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    c->graphs.push_back(g);
+    HIP_TRY(c, hipGraphLaunch(g.exec, c->stream));
+    c->main_touched = true;
     return WF_OK;
 }
 
@@ -504,10 +623,15 @@ int wf_destroy(wf_ctx *c)
     for (hipStream_t sd : c->side)
         if (sd) (void)hipStreamSynchronize(sd);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *pinned[] = { c->d_actions, c->d_reward, c->d_done, c->h_obs, c->h_dl };
+    for (wf_ctx::GraphEntry &g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    void *pinned[] = { c->d_actions, c->d_reward, c->d_done, c->h_obs, c->h_dl, c->p_out };
     for (void *b : pinned)
         if (b) (void)hipHostFree(b);
-    void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo, c->wind_cnt };
+    void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo, c->wind_cnt,
+                     c->v_actions, c->v_out };
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -675,63 +799,9 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
 {
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->fam == WF_FAM_WAVE) {
-        // Large batches: one launch per stream whose waves step their environments n_steps times (shapes with a
-        // rows-layout kernel), else n_steps single-step launches; both beat the fused one-environment-per-wave
-        // kernel there (4.2e11 cell-updates/s at 65 536 x 14x14), which serves small, launch-bound batches.
-        // The verdict is reached ONCE, from the shape of the whole call, and handed to every part launch
-        // (WfKnobs::multi_rows): a ragged last part must not fall back to another kernel on its own.
-        const bool sp = splits(c, 1);
-        const bool in_kernel = n_steps > 1 && (sp ? multi_rows_call(c, n_steps) : (c->knobs.multi_small && multi_rows_whole(c, n_steps)));
-        WfKnobs kn = c->knobs;
-        kn.multi_rows = in_kernel ? 1 : 0;
-        const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
-        const int n_launch = each ? n_steps : 1;
-        const size_t cells = (size_t)c->H * c->W;
-        for (int st = 0; st < n_launch; ++st) {
-            WfArgs a = base_args(c);
-            const size_t soff = (size_t)st * (size_t)c->batch;
-            a.obs = st == n_launch - 1 ? d_obs : nullptr;      // observation of the final state, written by the step kernel
-            a.actions = d_actions ? d_actions + soff : nullptr;
-            a.reward = d_reward ? d_reward + soff : nullptr;
-            a.done = d_done ? d_done + soff : nullptr;
-            a.n_steps = each ? 1 : n_steps;
-            a.update_mask = each ? (update_mask >> st) & 1ull : update_mask;
-            const bool split = splits(c, in_kernel ? 1 : a.n_steps);
-            if (!split) {
-                JOIN(c);
-                HIP_TRY(c, wf_launch_step(c->fam, a, kn, c->stream, c->num_cus));
-                continue;
-            }
-            // independent parts of the batch on separate streams (inputs must be complete when this is
-            // called: the context's own streams are not ordered with the caller's streams)
-            if (c->main_touched) {         // the sides must see earlier reset / upload / get_state work of `stream`
-                HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-                for (int i = 0; i < c->n_parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-                c->main_touched = false;
-            }
-            const int per = split_per(c);
-            if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);   // as for the whole batch
-            for (int i = 0; i < c->n_parts; ++i) {
-                const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
-                if (lo >= hi) break;
-                WfArgs ai = a;
-                ai.batch = hi - lo;
-                ai.env_base = (uint32_t)lo;
-                ai.planes = a.planes + (size_t)lo * cells;
-                ai.planes_out = ai.planes;
-                ai.envs = a.envs + lo;
-                ai.reach = a.reach + (size_t)lo * 4;
-                if (a.actions) ai.actions = a.actions + lo;
-                if (a.reward) ai.reward = a.reward + lo;
-                if (a.done) ai.done = a.done + lo;
-                if (a.obs) ai.obs = a.obs + (size_t)lo * cells * 3;
-                HIP_TRY(c, wf_launch_step(c->fam, ai, kn, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
-            }
-            c->side_pending = true;
-        }
-        return WF_OK;
-    }
+    if (c->fam == WF_FAM_WAVE)
+        return (c->knobs.graph && c->own_stream) ? wave_step_graph(c, d_actions, n_steps, update_mask, d_reward, d_done, d_obs)
+                                                 : wave_step_issue(c, d_actions, n_steps, update_mask, d_reward, d_done, d_obs);
     // big-grid families: one launch sequence per step, source planes -> destination planes.  Large jobs on
     // the context's own streams run as n_parts independent shares of the batch on separate streams: the
     // small lanes = environments kernels of one share overlap the streaming kernel of the other.
@@ -800,13 +870,38 @@ int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_m
     const size_t n = (size_t)n_steps * (size_t)c->batch;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
-    if (actions) memcpy(c->d_actions, actions, n);          // pinned: the kernels read it in place
     const size_t nobs = (size_t)c->batch * c->H * c->W * 3;
     const bool zc_obs = obs && nobs <= WF_ZC_OBS_MAX;
     if (zc_obs && !c->h_obs) HIP_TRY(c, hipHostMalloc((void **)&c->h_obs, nobs, hipHostMallocDefault));
     if (obs && !zc_obs && !c->d_obs) HIP_TRY(c, hipMalloc((void **)&c->d_obs, nobs));
+    int8_t *obs_dst = !obs ? nullptr : zc_obs ? c->h_obs : c->d_obs;
+    const size_t stage_min = c->knobs.host_stage_min > 0 ? (size_t)c->knobs.host_stage_min : (size_t)16384;
+    if (n >= stage_min) {
+        // large batch: actions in and reward / done out through device mirrors and one copy kernel each way
+        if ((rc = ensure_mirrors(c, n)) != WF_OK) return rc;
+        if (actions) {
+            memcpy(c->d_actions, actions, n);
+            HIP_TRY(c, wf_launch_copy_words(c->d_actions, c->v_actions, (n + 3) & ~(size_t)3, c->stream));
+        }
+        double *v_reward = reinterpret_cast<double *>(c->v_out);
+        uint8_t *v_done = c->v_out + n * sizeof(double);
+        rc = wf_step_obs_device(c, actions ? c->v_actions : nullptr, n_steps, update_mask, reward ? v_reward : nullptr, done ? v_done : nullptr, obs_dst);
+        if (rc != WF_OK) return rc;
+        JOIN(c);
+        if (reward || done) {
+            const size_t lo = reward ? 0 : n * sizeof(double), hi = done ? n * 9 : n * sizeof(double);
+            HIP_TRY(c, wf_launch_copy_words(c->v_out + lo, c->p_out + lo, (hi - lo + 3) & ~(size_t)3, c->stream));
+        }
+        if (obs && !zc_obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (zc_obs) memcpy(obs, c->h_obs, nobs);
+        if (reward) memcpy(reward, c->p_out, n * sizeof(double));
+        if (done) memcpy(done, c->p_out + n * sizeof(double), n);
+        return WF_OK;
+    }
+    if (actions) memcpy(c->d_actions, actions, n);          // pinned: the kernels read it in place
     rc = wf_step_obs_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask,
-                            reward ? c->d_reward : nullptr, done ? c->d_done : nullptr, !obs ? nullptr : zc_obs ? c->h_obs : c->d_obs);
+                            reward ? c->d_reward : nullptr, done ? c->d_done : nullptr, obs_dst);
     if (rc != WF_OK) return rc;
     JOIN(c);
     if (obs && !zc_obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));

@@ -74,6 +74,8 @@ struct WfKnobs {
     int family;       // WF_FAMILY=cells (1) / tiled (2): kernel family override, honoured by wf_create only
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
+    int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = 16 384)
+    int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
     int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop
 };
 void wf_read_knobs(WfKnobs *k);

@@ -417,6 +417,11 @@ __global__ __launch_bounds__(256) void wf_copy_words_kernel(const uint32_t *src,
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void wf_copy_quads_kernel(const uint4 *src, uint4 *dst, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void wf_invalidate_reach_kernel(wf_env *envs, int batch)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -488,10 +493,11 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         const dim3 grid_private((waves + 3) / 4), grid_shared((a.batch + 63) / 64), block_shared(64 * (64 / p.G));
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
-            if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false>), grid_private, dim3(256), 0, s, g);
-            if (p.kind == STEP_ROWS && a.n_steps > 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true>), grid_private, dim3(256), 0, s, g);
-            if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false>), grid_private, dim3(256), 0, s, g);
-            if (p.kind == STEP_ROWS && a.n_steps <= 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, true>), grid_private, dim3(256), 0, s, g);
+            const dim3 grid_rows((waves + WF_ROWS_WPB - 1) / WF_ROWS_WPB), block_rows(64 * WF_ROWS_WPB);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false>), grid_rows, block_rows, 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true>), grid_rows, block_rows, 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false>), grid_rows, block_rows, 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, true>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS_SHARED) {
                 // WF_SHARED=N with N in {2,4,8}: N waves share the agent phases (N*G <= 64 environments per workgroup)
                 int nw = k.shared;
@@ -549,6 +555,8 @@ void wf_read_knobs(WfKnobs *k)
     k->cells_legacy = set("WF_CELLS_LEGACY");
     const char *fam = getenv("WF_FAMILY");
     k->family = !fam ? 0 : !strcmp(fam, "cells") ? 1 : !strcmp(fam, "tiled") ? 2 : 0;
+    k->graph = set("WF_GRAPH");
+    k->host_stage_min = num("WF_HOST_STAGE_MIN", 0);
     k->multi_rows = 0;
 }
 
@@ -634,6 +642,13 @@ hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num
 
 hipError_t wf_launch_copy_words(const void *src, void *dst, size_t bytes, hipStream_t s)
 {
+    if (bytes >= 65536 && bytes % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+        const uint32_t nq = (uint32_t)(bytes / 16);          // large copies: 16 bytes per lane
+        unsigned blocks = (nq + 255u) / 256u;
+        if (blocks > 1024u) blocks = 1024u;
+        hipLaunchKernelGGL(wf_copy_quads_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), nq);
+        return hipGetLastError();
+    }
     const uint32_t n = (uint32_t)(bytes / 4);
     unsigned blocks = (n + 255u) / 256u;
     if (blocks > 1024u) blocks = 1024u;

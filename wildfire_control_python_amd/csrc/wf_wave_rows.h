@@ -250,13 +250,18 @@ __device__ __forceinline__ void set_progress_prio(uint32_t done, uint32_t total)
 #endif
 }
 
+// Waves per workgroup of the private (not workgroup-shared) variant.  The dispatcher hands out workgroups, so fewer,
+// larger ones mean fewer dispatches per launch (8 192 waves = 2 048 / 1 024 / 512 workgroups for 4 / 8 / 16).
+#ifndef WF_ROWS_WPB
+#define WF_ROWS_WPB 4
+#endif
 // MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
 template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE>
 // Waves per SIMD: minimum = maximum = 8.  (A minimum of 7 gives the register allocator 94 scalar registers instead of
 // 80 and removes a third of the scalar spills to VGPR lanes, and the compiler still reports 8 waves per SIMD - but a
 // wave's 94 SGPRs are allocated as 112, 800 / 112 = 7: tools/wave_timeline.py showed exactly one workgroup in eight
 // starting 10 us late.  Same step time either way; 8 resident waves is what the launch geometry assumes.)
-__global__ __launch_bounds__(SHARED ? 512 : 256)
+__global__ __launch_bounds__(SHARED ? 512 : 64 * WF_ROWS_WPB)
 __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN, MULTI ? WF_LB_ROWS_MULTI : WF_LB_ROWS), amdgpu_num_sgpr(102))) void wf_step_rows(const WfArgs a0)
 {
     using R = RG<W, H, S>;
@@ -276,7 +281,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         e0 = A0 + gi0;
         ng = gi0 < na ? min(G, na - gi0) : 0u;
     } else {
-        e0 = rfl(blockIdx.x * 4u + wv) * G;
+        e0 = rfl(blockIdx.x * (uint32_t)WF_ROWS_WPB + wv) * G;
         if (e0 >= batch) return;
         ng = min(G, batch - e0);
         A0 = e0;
@@ -317,7 +322,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     char *planes_b = reinterpret_cast<char *>(a.planes);
     // (this launch's planes; 32-bit byte offsets - wf_create keeps a context's planes below 4 GiB)
     const __amdgpu_buffer_rsrc_t planes_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.planes, 0, (int)(batch * ENV_BYTES), 0x00020000);
-    __shared__ uint32_t sS[7][SHARED ? 64 : 128];            // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
+    __shared__ uint32_t sS[7][SHARED ? 64 : 32 * WF_ROWS_WPB];   // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
     enum { S_POS = 0, S_FL = 1, S_EP = 2, S_TICK = 3, S_P = 4, S_R = 5, S_CNT = 6 };
 
     // ================= phase A: lanes = environments =================
@@ -357,7 +362,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     asm volatile("" : "+v"(bgeo), "+v"(ob));
     const uint32_t K_FIRE_STEP = 0x0000FF01u;                // low half: fuel byte -1, type byte +1 (fire -> burnt); pk_add_u16
     constexpr int OBS_PAD = (EPW * OBS_BYTES + 15) & ~15;
-    __shared__ __attribute__((aligned(16))) uint8_t sObs[SHARED ? 8 : 4][OBS_PAD];
+    __shared__ __attribute__((aligned(16))) uint8_t sObs[SHARED ? 8 : WF_ROWS_WPB][OBS_PAD];
     uint8_t *obs_lds = sObs[wv];
     typedef const u64 __attribute__((address_space(4))) *const_u64_ptr;
 
