@@ -155,16 +155,36 @@ def cpu_baseline(size, seed, seconds):
     return out
 
 
-def measured_traffic(batch, size):
-    """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC
-    passes (profiles/traffic.json; bench.py cannot collect PMC counters on itself)."""
+def kernel_source_sha256():
+    """Hash of the kernel and ABI sources the loaded library was built from (the .so itself is not reproducible byte for
+    byte; the sources are).  profiles/traffic.json carries the hash of the sources its counters were collected with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(REPO, "wildfire_control_python_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.cpp"))
+                    + [os.path.join(REPO, "include", "wildfire.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(leg, algorithmic_bytes):
+    """(bytes, note): L2 <-> fabric bytes per launch of the leg's dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/collect_profiles.py; a process cannot collect PMC counters on itself).
+    FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE.  None when the passes were collected with other
+    kernel sources than the ones in this tree, or for another workload size."""
     try:
         t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        if t["algorithmic_bytes_per_launch"] == BYTES_PER_CELL_UPDATE * batch * size * size:
-            return t["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+        e = t["legs"][leg]
+        if t.get("kernel_source_sha256") != kernel_source_sha256():
+            return None, "profiles/traffic.json was collected with other kernel sources: stale, not reported"
+        if e["algorithmic_bytes_per_launch"] != algorithmic_bytes:
+            return None, "profiles/traffic.json holds another workload size for this leg"
+        return e["traffic_bytes_per_launch"], (f"{e['pmc_pass']}; L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included"
+                                               + ("" if e["state_bytes"] > 256 << 20 else "; the state fits the 256 MB Infinity Cache: not HBM traffic"))
+    except Exception as ex:
+        return None, f"profiles/traffic.json: {ex!r}"
 
 
 # ------------------------------------------------------------------ --gpus N without a launcher
@@ -239,6 +259,22 @@ def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call
     cells = B * S * S
     us = ms / steps * 1e3
     achieved = BYTES_PER_CELL_UPDATE * cells * n / (us * 1e-6) / 1e9
+    traffic, traffic_note = measured_traffic(name, BYTES_PER_CELL_UPDATE * cells * n)
+    get_state = None
+    if name == "c4":
+        # World.get_state() of the whole batch as its own call (what reset() returns; the step kernels write it themselves)
+        d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
+        for _ in range(3):
+            env.get_state_device(d_obs)
+        env.sync()
+        env.timer_start()
+        for _ in range(20):
+            env.get_state_device(d_obs)
+        gus = env.timer_stop() / 20 * 1e3
+        gbs = 7 * cells / (gus * 1e-6) / 1e9
+        get_state = {"us_per_call": gus, "bytes_per_cell": 7, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "kernel": "wf_get_state_cols (LDS-tiled transpose)"}
+        del d_obs
     out = {"workload": f"{B} x {S}x{S}, fuel U{{10..40}}, " + ("no-op actions" if noop else "uniform N/S/E/W actions") +
                        (f", {ppm} ppm pre-ignited" if ppm else "") + (f", wind {wind!r} (environment.py:187-193)" if wind else "") + f", containment {'on' if env.containment else 'off'}, auto-reset"
                        + (f", env ids from {env_id0}" if env_id0 else "") + f" ({config_label(S, B, noop, ppm)})",
@@ -246,11 +282,14 @@ def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call
            "cell_updates_per_s": cells * n * steps / (ms * 1e-3),
            "state_bytes": cells * 4,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "kernel": env.step_kernel if n == 1 or env._lib.wf_call_launches(env._h, n) > 1 else "wf_step_wave (fused ticks)",
+                        "kernel": env._lib.wf_call_kernel_name(env._h, n).decode(),
                         "launches_per_call": int(env._lib.wf_call_launches(env._h, n)),
                         "algorithmic_bytes_per_call": BYTES_PER_CELL_UPDATE * cells * n,
+                        "traffic": traffic, "traffic_note": traffic_note,
                         "note": "8 B per cell-update x ticks per call; fused ticks keep the grid in registers, so HBM moves 8 B per cell per CALL"
                                 if n > 1 else "8 B per cell-update"}}
+    if get_state:
+        out["get_state"] = get_state
     env.close()
     del d_act, d_rew, d_done
     torch.cuda.empty_cache()
@@ -416,7 +455,33 @@ def main():
             env.step_many(a_np[s])
         th = time.perf_counter() - th
         host_api = {"cell_updates_per_s": cells * 29 / th, "us_per_step": th / 29 * 1e6,
-                    "note": "wf_step(): numpy in / out; the kernels read actions from and write reward/done to pinned host memory + stream sync per step"}
+                    "note": "wf_step(): numpy in / out, PCIe and host synchronisation included; at this size actions / reward / done travel "
+                            "through device mirrors and one copy kernel each way (small batches: the kernels read and write pinned host memory)"}
+
+    # extra: the single-environment drop-in the reference's learners call (ForestFire.step: numpy in / out, the host view
+    # refreshed after every step), against the reference's own Python step timed in the build container
+    adapter = None
+    if world == 1 and not args.no_extras:
+        from wildfire_control_python_amd import ForestFire
+        sim = ForestFire(size=S, device=local)
+        np.random.seed(1)
+        sim.reset()
+        arng = np.random.default_rng(0)
+        for _ in range(50):
+            if sim.step(int(arng.integers(0, 4)))[2]:
+                sim.reset()
+        n_a, ta = 0, time.perf_counter()
+        while n_a < 1500:
+            _, _, dn, _ = sim.step(int(arng.integers(0, 4)))
+            n_a += 1
+            if dn:
+                sim.reset()
+        ta = (time.perf_counter() - ta) / n_a
+        sim.close()
+        ref = reference_python_numbers(S)
+        adapter = {"us_per_step": ta * 1e6, "grid": [S, S], "resets_included": True,
+                   "reference_python_us_per_step": (S * S / ref["cell_updates_per_s_1_process"] * 1e6) if ref else None,
+                   "note": "ForestFire(size).step(action) -> [state, reward, done, {}] (forest_fire.py:30-49), one environment, host round trip per step"}
 
     kernel_name, step_kernel, step_launches, containment = env.kernel_name, env.step_kernel, env.step_launches, env.containment
     env.close()
@@ -447,6 +512,8 @@ def main():
     if rank == 0:
         value = cells * world * steps_timed / wall_max
         launch_ms = ev_max / steps_timed
+        traffic, traffic_note = measured_traffic("c3" if (S, B) == (14, 65536) else "c5_shard" if (S, B) == (14, 125000) else "custom",
+                                                 BYTES_PER_CELL_UPDATE * cells)
         achieved = BYTES_PER_CELL_UPDATE * cells / (launch_ms * 1e-3) / 1e9
         out = {
             "metric": "cell-updates/sec",
@@ -475,13 +542,16 @@ def main():
             # one step = `launches_per_step` concurrent launches of `kernel` on separate streams, each over an
             # equal share of the batch; achieved = algorithmic bytes of the whole step / HIP-event time per step
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, S),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": step_kernel, "launches_per_step": step_launches,
                          "launch_us": launch_ms * 1e3,
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells,
                          "note": ("launch_us/bytes are per STEP (all concurrent launches of it); "
                                   "single_launch = the same step as one launch, comparable with rocprofv3 kernel stats")},
             "done_frac_last_step": done_frac,
+            # `value` is the step alone (reward and done written, no observation).  A learner that wants World.get_state()
+            # after every step pays step_plus_observation.fused_us_per_step (11 B per cell-update: + 3 B of observation)
+            "value_includes_observation": False,
         }
         if single_ms is not None:
             a1 = BYTES_PER_CELL_UPDATE * cells / (single_ms * 1e-3) / 1e9
@@ -492,6 +562,8 @@ def main():
             out["step_plus_observation"] = obs_extra
         if host_api:
             out["host_buffer_api"] = host_api
+        if adapter:
+            out["single_env_adapter"] = adapter
         if legs:
             out["configs"] = legs
         if cpu is not None:

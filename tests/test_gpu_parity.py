@@ -566,6 +566,77 @@ def test_multi_step_call_in_one_launch_matches_single_steps_and_oracle(wf, monke
     b_env.close()
 
 
+@pytest.mark.parametrize("W,H,B,md", [(10, 10, 4096, None), (10, 10, 2048 + 37, None), (14, 14, 2048 + 3, {"allow_dig_toggle": True, "n_actions": 5}),
+                                      (8, 8, 4096 + 11, None), (16, 8, 3000, {"make_rivers": True}), (12, 12, 9000, {"make_rivers": True, "allow_dig_toggle": True, "n_actions": 5}),
+                                      (14, 14, 16384 + 77, None)])
+def test_resident_step_loop_matches_plain_loop_and_oracle(wf, monkeypatch, W, H, B, md):
+    """n-step calls on the rows kernel's RESIDENT step loop (cells in an LDS mirror for the whole call, records handed
+    from step to step through LDS): small batches that are not split, ragged last waves, shapes with 2 / 3 / 7
+    environments per wave iteration, dig toggle and rivers, auto-resets and containment floods inside the loop - equal to
+    the loop through L2 and to the oracle, observation of the final state included."""
+    import ctypes
+    from wildfire_control_python_amd import _native as N
+    n, calls = 16, 5
+    toggle = bool(md and md.get("allow_dig_toggle"))
+    kw = dict(width=W, height=H, seed=33, auto_reset=True, containment=True, fuel_range=(3, 9), metadata=md)
+    monkeypatch.setenv("WF_RESIDENT", "1")                    # (an opt-in experiment: measured no faster than the loop through L2)
+    monkeypatch.setenv("WF_MULTI_SMALL", "1")                 # batches that are not split take the step loop too
+    a_env = wf.BatchedForestFire(B, **kw)                     # both read at construction
+    monkeypatch.delenv("WF_RESIDENT", raising=False)
+    b_env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_MULTI_SMALL", raising=False)
+    name = a_env._lib.wf_call_kernel_name(a_env._h, n).decode()
+    assert "LDS-resident" in name and "LDS-resident" not in b_env._lib.wf_call_kernel_name(b_env._h, n).decode(), name
+    a_env.reset(seed=33)
+    b_env.reset(seed=33)
+    op = O.default_params(containment=1, fuel_lo=3, fuel_hi=9, allow_dig_toggle=int(toggle), make_rivers=int(bool(md and md.get("make_rivers"))))
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=33, params=op)
+    rng = np.random.default_rng(B)
+    paid = resets = 0
+    for call in range(calls):
+        a = rng.integers(0, 6, size=(n, B)).astype(np.int8)
+        for k in range(0, n, 2):
+            a[k, :B // 2] = _circle_actions(envs[:B // 2], W, H, rng)        # (stale after the first step: still ring-ish diggers)
+        mask = (1 << n) - 1 if call % 2 == 0 else 0b1011011101101101
+        ra, da = np.empty((n, B)), np.empty((n, B), dtype=np.uint8)
+        rb, db = np.empty((n, B)), np.empty((n, B), dtype=np.uint8)
+        obs_a = np.empty((B, W, H, 3), dtype=np.int8)
+        obs_b = np.empty_like(obs_a)
+        assert a_env._lib.wf_step_obs(a_env._h, N.ptr(a), n, ctypes.c_uint64(mask), N.ptr(ra), N.ptr(da), N.ptr(obs_a)) == 0
+        assert b_env._lib.wf_step_obs(b_env._h, N.ptr(a), n, ctypes.c_uint64(mask), N.ptr(rb), N.ptr(db), N.ptr(obs_b)) == 0
+        for k in range(n):
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, a[k], op, do_update=bool((mask >> k) & 1))
+            if stopped.any():
+                O.reset(planes, envs, seed=33, mask=stopped, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+                resets += int(stopped.sum())
+            np.testing.assert_array_equal(ra[k], ro, err_msg=f"reward vs oracle call {call} step {k}")
+            np.testing.assert_array_equal(da[k], do, err_msg=f"done vs oracle call {call} step {k}")
+            paid += int((ro == 1000.0).sum())
+        np.testing.assert_array_equal(ra, rb, err_msg=f"reward call {call}")
+        np.testing.assert_array_equal(da, db, err_msg=f"done call {call}")
+        np.testing.assert_array_equal(obs_a, O.get_state(planes), err_msg=f"obs vs oracle call {call}")
+        np.testing.assert_array_equal(obs_a, obs_b, err_msg=f"obs call {call}")
+        gp, ge = a_env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes call {call}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs call {call}")
+        # a single step in between: the single-step kernels must find the boards and records the loop left
+        a1 = rng.integers(0, 6, size=B).astype(np.int8)
+        _, r1, d1, _ = a_env.step(a1)
+        b_env.step(a1)
+        stopped = (envs["flags"] & O.F_RUNNING) == 0
+        ro, do = O.step(planes, envs, a1, op)
+        if stopped.any():
+            O.reset(planes, envs, seed=33, mask=stopped, params=op)
+            ro[stopped], do[stopped] = 0.0, 0
+        np.testing.assert_array_equal(r1, ro, err_msg=f"single step after call {call}")
+    assert resets > B // 8, resets
+    a_env.close()
+    b_env.close()
+
+
 def test_fused_multi_step_observation(wf):
     """wf_step_obs with n_steps > 1: the observation is that of the final state."""
     import ctypes

@@ -10,10 +10,14 @@ import wildfire_control_python_amd as pkg
 B, S, T = 4096, 10, 16
 for B in (4096, 2048, 8192):
     env = pkg.BatchedForestFire(B, size=S, seed=1234, auto_reset=True, fuel_range=(10, 40))
-    for name, kv in (("fused (default)", {}), ("rows loop G=3", {"WF_MULTI_SMALL": "1", "WF_GROUP": "3"}),
-                     ("rows loop G=6", {"WF_MULTI_SMALL": "1", "WF_GROUP": "6"}), ("rows loop G=12", {"WF_MULTI_SMALL": "1", "WF_GROUP": "12"}),
+    for name, kv in (("default", {}), ("fused, 1 env per wave", {"WF_NO_MULTI": "1"} if B >= 8192 else {}),
+                     ("resident loop G=2", {"WF_RESIDENT": "1", "WF_MULTI_SMALL": "1", "WF_GROUP": "2"}),
+                     ("resident loop G=4", {"WF_RESIDENT": "1", "WF_MULTI_SMALL": "1", "WF_GROUP": "4"}),
+                     ("resident loop G=8", {"WF_RESIDENT": "1", "WF_MULTI_SMALL": "1", "WF_GROUP": "8"}),
+                     ("loop through L2 G=2", {"WF_MULTI_SMALL": "1", "WF_GROUP": "2"}),
+                     ("loop through L2 G=4", {"WF_MULTI_SMALL": "1", "WF_GROUP": "4"}),
                      ("16 single steps", None)):
-        for k in ("WF_MULTI_SMALL", "WF_GROUP"):
+        for k in ("WF_MULTI_SMALL", "WF_GROUP", "WF_RESIDENT", "WF_NO_MULTI"):
             os.environ.pop(k, None)
         os.environ.update(kv or {})
         env.reload_env()
@@ -36,6 +40,7 @@ for B in (4096, 2048, 8192):
         ms = env.timer_stop()
         wall = time.perf_counter() - t0
         cu = B * S * S * T * n / (ms * 1e-3)
-        print(f"B={B:5d} {name:18s}: {ms / n * 1e3:7.2f} us per {T}-tick call (wall {wall / n * 1e6:7.2f}), {cu:.3e} cell-updates/s, "
+        kname = env._lib.wf_call_kernel_name(env._h, T).decode() if kv is not None else env.step_kernel
+        print(f"B={B:5d} {name:22s} [{kname[:60]}]: {ms / n * 1e3:7.2f} us per {T}-tick call (wall {wall / n * 1e6:7.2f}), {cu:.3e} cell-updates/s, "
               f"{cu * 8 / 8e12:.3f} of the HBM roofline", flush=True)
     env.close()

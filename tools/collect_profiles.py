@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/prof_{tag}"
 
 RUNS = [  # (directory, what was run)
@@ -16,6 +16,10 @@ RUNS = [  # (directory, what was run)
               "wf_step_rows, so their durations overlap; the calls also hold the extra legs' launches: c2 / c4 / c5_shard / hbm_1m)"),
     ("kt_c3_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline   (65 536 x 14x14, ONE launch per step: compare "
                      "AverageNs with roofline.single_launch.launch_us of the bench line)"),
+    ("kt_c3_split", "python3 bench.py --no-extras --no-cpu-baseline --steps 1500 --warmup 100   (65 536 x 14x14, the DEFAULT step: two concurrent "
+                    "half-batch launches per step on two streams - a launch lasts about one step period because the two share the chip; "
+                    "the per-launch records are summarised in profiles/<tag>_c3_split_trace.json)"),
+    ("kt_c5", "python3 bench.py --no-extras --no-cpu-baseline --batch 125000 --steps 400 --warmup 40   (one shard of BASELINE configs[4])"),
     ("kt_c4", "python3 bench.py --no-extras --no-cpu-baseline --size 256 --batch 1024 --noop --ignite-ppm 10000 --steps 200 --warmup 20"
               "   (BASELINE configs[3]; a step = 3 concurrent launch sequences on 3 streams, each over a third of the batch)"),
     ("kt_c4_single", "WF_NO_SPLIT=1, same command   (BASELINE configs[3], one launch sequence per step: the per-kernel durations add up to the step)"),
@@ -52,7 +56,8 @@ def counters(d):
 lines, vals = [], {}
 for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
                         ("c4", "wf_step_tiled", "1 024 x 256x256 (268 MB; WF_NO_SPLIT=1, ticks 60..120 after the reset, --min-ms 0)"),
-                        ("hbm", "wf_step_rows", "1 048 576 x 14x14 (822 MB; WF_NO_SPLIT=1, steps 60..100, --min-ms 0)")):
+                        ("hbm", "wf_step_rows", "1 048 576 x 14x14 (822 MB; WF_NO_SPLIT=1, steps 60..100, --min-ms 0)"),
+                        ("c5", "wf_step_rows", "125 000 x 14x14 (98 MB, one shard of configs[4]; WF_NO_SPLIT=1, --steps 40 --warmup 400)")):
     lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
     for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
         if not os.path.isdir(d):
@@ -93,6 +98,17 @@ t["other_sizes"] = {
     "c4_tiled": traffic("c4", "wf_step_tiled", 1024 * 65536, "1024 x 256x256, 10000 ppm pre-ignited, no-op, ticks 60..120 (268 MB: past the Infinity Cache)"),
     "hbm_1m": traffic("hbm", "wf_step_rows<14,14,2,false>", 1048576 * 196, "1048576 x 14x14, bench inputs (822 MB: true HBM streaming)"),
 }
+t["other_sizes"]["c5_shard"] = traffic("c5", "wf_step_rows<14,14,2,false>", 125000 * 196, "125000 x 14x14, bench inputs (98 MB: one shard of BASELINE configs[4])")
+# what bench.py looks up, per leg of its JSON line; every entry names the PMC pass it came from
+t["kernel_source_sha256"] = open(f"{src}/kernel_source_sha256.txt").read().strip()
+t["legs"] = {}
+for leg, key, cfg in (("c3", None, "c3"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5")):
+    e = dict(t if key is None else t["other_sizes"][key])
+    for k in ("other_sizes", "legs", "note", "round", "kernel_source_sha256"):
+        e.pop(k, None)
+    e["pmc_pass"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gpurun_out/prof_{tag}/pmc_{cfg}_*, "
+                     f"summary in profiles/{tag}_pmc_summary.txt")
+    t["legs"][leg] = e
 c4 = t["other_sizes"]["c4_tiled"]
 c4["changed_quad_bytes_per_tick"] = amp["mean_changed_quad_bytes"]
 c4["changed_128B_line_bytes_per_tick"] = amp["mean_changed_line_bytes"]
@@ -101,6 +117,8 @@ c4["note"] = ("a lane stores its 16-byte quad only if one of its four cells chan
               "same tick window); WRITE_SIZE / changed-quad bytes = write amplification of whole dirty lines leaving L2")
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 shutil.copy(f"{src}/bench_plain.json", f"profiles/{tag}_bench_plain.json")
+shutil.copy(f"{src}/c3_split_trace.json", f"profiles/{tag}_c3_split_trace.json")
+shutil.copy(f"{src}/c3_split_trace_excerpt.csv", f"profiles/{tag}_c3_split_trace_excerpt.csv")
 print(open(f"profiles/{tag}_kernel_stats.csv").read()[:6000])
 print(open(f"profiles/{tag}_pmc_summary.txt").read())
 print(json.dumps(t, indent=1))

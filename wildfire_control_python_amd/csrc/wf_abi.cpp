@@ -378,7 +378,8 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
     // The verdict is reached ONCE, from the shape of the whole call, and handed to every part launch
     // (WfKnobs::multi_rows): a ragged last part must not fall back to another kernel on its own.
     const bool sp = splits(c, 1);
-    const bool in_kernel = n_steps > 1 && (sp ? multi_rows_call(c, n_steps) : (c->knobs.multi_small && multi_rows_whole(c, n_steps)));
+    const bool in_kernel = n_steps > 1 && (sp ? multi_rows_call(c, n_steps)
+                                              : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps)));
     WfKnobs kn = c->knobs;
     kn.multi_rows = in_kernel ? 1 : 0;
     const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
@@ -980,6 +981,22 @@ const char *wf_step_kernel_name(const wf_ctx *c)
         a.batch = split_per(c);
     }
     return wf_single_step_kernel(c->fam, a, c->knobs, c->num_cus);
+}
+
+const char *wf_call_kernel_name(const wf_ctx *c, int n_steps)
+{
+    if (!c || n_steps < 1) return "none";
+    if (n_steps == 1 || c->fam != WF_FAM_WAVE) return wf_step_kernel_name(c);
+    const bool sp = splits(c, 1);
+    const bool in_kernel = sp ? multi_rows_call(c, n_steps) : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps));
+    if (!in_kernel) return sp ? wf_step_kernel_name(c) : "wf_step_wave (fused ticks, one environment per wave)";
+    WfArgs a = base_args(c);
+    a.n_steps = n_steps;
+    if (sp) {
+        a.batch = split_per(c);
+        if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);
+    }
+    return wf_multi_step_kernel(a, c->knobs, c->num_cus);
 }
 
 int wf_call_launches(const wf_ctx *c, int n_steps)

@@ -75,6 +75,7 @@ struct WfKnobs {
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = 16 384)
+    int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
     int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop
 };
@@ -111,6 +112,7 @@ const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &
 // n_steps > 1 served by ONE launch of the rows kernel (decided ONCE per call from the whole call's shape; the
 // verdict travels to the part launches in WfKnobs::multi_rows)
 bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus);
+const char *wf_multi_step_kernel(const WfArgs &a, const WfKnobs &k, int num_cus);
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus);
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
 // big-grid families (wf_tiled.hip, wf_generic.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out

@@ -458,6 +458,12 @@ StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
     p.G = wf_pick_group_for(W, H, num_cus, a.batch, k);
     const int gmax = wf_pick_group(W * H, num_cus, 1ll << 40);
     if (a.group > 0) p.G = a.group < gmax ? a.group : gmax;
+    if constexpr (HasRows<W, H>::value) {
+        // an n-step call: at least one iteration's worth of environments per wave, so that the rows kernel's step loop
+        // can serve it (8 192 x 10x10 x 16 ticks: 48 us with 2 environments per wave against 104 as 16 single steps)
+        constexpr int EPW0 = RG<W, H, HasRows<W, H>::S>::EPW;
+        if (a.n_steps > 1 && p.G < EPW0) p.G = EPW0;
+    }
     // (the workgroup-shared experiment exists for the reference's default options only)
     const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096 && !(a.hot_flags & WF_HOT_RARE);
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
@@ -494,8 +500,13 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
             const dim3 grid_rows((waves + WF_ROWS_WPB - 1) / WF_ROWS_WPB), block_rows(64 * WF_ROWS_WPB);
-            if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false>), grid_rows, block_rows, 0, s, g);
-            if (p.kind == STEP_ROWS && a.n_steps > 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true>), grid_rows, block_rows, 0, s, g);
+            // step loop: LDS-resident when the wave's environments fit its mirror (WF_NO_RESIDENT: the plain loop)
+            const bool res = !k.no_resident && p.G <= WF_RES_MAXG;
+            const size_t mirror_bytes = (size_t)WF_ROWS_WPB * p.G * W * H * 4;
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare && res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false, true>), grid_rows, block_rows, mirror_bytes, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && rare && res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true, true>), grid_rows, block_rows, mirror_bytes, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare && !res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false>), grid_rows, block_rows, 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps > 1 && rare && !res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS && a.n_steps <= 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, true>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS_SHARED) {
@@ -555,6 +566,7 @@ void wf_read_knobs(WfKnobs *k)
     k->cells_legacy = set("WF_CELLS_LEGACY");
     const char *fam = getenv("WF_FAMILY");
     k->family = !fam ? 0 : !strcmp(fam, "cells") ? 1 : !strcmp(fam, "tiled") ? 2 : 0;
+    k->no_resident = !set("WF_RESIDENT");     // opt-in experiment (measured: no gain, profiles/r03_c2_variants.txt)
     k->graph = set("WF_GRAPH");
     k->host_stage_min = num("WF_HOST_STAGE_MIN", 0);
     k->multi_rows = 0;
@@ -603,6 +615,8 @@ const char *wf_family_name(WfFamily f, int, int)
 // stepping its environments n_steps times (small batches: the fused one-environment-per-wave kernel).
 bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus)
 {
+    // (below 4 096 environments per launch the one-environment-per-wave kernel has more waves to hide its latency with:
+    // 4 096 x 10x10 x 16 ticks 37.7 us against 42.1 on the step loop with 2 environments per wave)
     if (fam != WF_FAM_WAVE || a.step_stride <= 0 || a.batch < 4096 || k.no_multi) return false;
     StepPlan p = { 0, -1 };
 #define X(w, h) if (a.W == w && a.H == h) p = plan_single<w, h>(a, k, num_cus);
@@ -625,6 +639,21 @@ const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &
     if (p.kind < 0) return "none";
     if (p.kind >= STEP_ROWS) snprintf(buf, sizeof buf, "wf_step_rows<%d,%d,%d,%s>", a.W, a.H, S, p.kind == STEP_ROWS_SHARED ? "true" : "false");
     else snprintf(buf, sizeof buf, "wf_step_group<%d,%d,%s>", a.W, a.H, p.kind == STEP_GROUP_SHARED ? "true" : "false");
+    return buf;
+}
+
+// symbol of the kernel behind an n_steps call whose verdict (WfKnobs::multi_rows) says "rows step loop"
+const char *wf_multi_step_kernel(const WfArgs &a, const WfKnobs &k, int num_cus)
+{
+    static thread_local char buf[96];
+    StepPlan p = { 0, -1 };
+    int S = 1;
+#define X(w, h) if (a.W == w && a.H == h) { p = plan_single<w, h>(a, k, num_cus); S = HasRows<w, h>::S; }
+    WF_WAVE_SHAPES(X)
+#undef X
+    if (p.kind != STEP_ROWS) return "none";
+    snprintf(buf, sizeof buf, "wf_step_rows<%d,%d,%d> step loop, %s, %d environments per wave", a.W, a.H, S,
+             (!k.no_resident && p.G <= WF_RES_MAXG) ? "LDS-resident" : "through L2", p.G);
     return buf;
 }
 

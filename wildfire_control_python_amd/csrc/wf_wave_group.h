@@ -29,14 +29,17 @@ struct EnvRegs {
 // Phase A for the environment of this lane: Agent.move / toggle / death, the containment ring
 // verdict, and the touched bytes applied to the grid in memory.  Returns the env's registers;
 // Pv = PB_* bits for phase B (bit 0 = the env was running when the step began).
-template <int W, int H, int VB, bool RARE>
-__device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lane_env, const uint32_t ek, const bool do_update)
+// PRE: the record comes in `pre` (a resident step loop keeps it in LDS between its steps) instead of from a.envs.
+template <int W, int H, int VB, bool RARE, bool PRE = false>
+__device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lane_env, const uint32_t ek, const bool do_update,
+                                                 const uint4 pre = make_uint4(0, 0, 0, 0))
 {
     constexpr int CELLS = W * H;
     constexpr uint32_t ENV_BYTES = CELLS * 4;
     char *planes_b = reinterpret_cast<char *>(a.planes);
     const uint32_t pbase = ek * ENV_BYTES;
-    const uint4 ev = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + ek * 16u);
+    uint4 ev = pre;
+    if constexpr (!PRE) ev = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + ek * 16u);
     const uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[ek] : 0xffu;
     uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu, episode = ev.z, tick = ev.w;
     const uint32_t running = (fl >> 4) & 1u & (lane_env ? 1u : 0u);
@@ -137,9 +140,10 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
 }
 
 // Phase C for the environment of this lane: flags, reward, done, record (Rv = RB_* bits of phase B).
+// Returns the environment's record as written (x | y << 16, flags, episode, tick).
 template <int W, int H, int VB>
-__device__ __forceinline__ void group_phase_c(const WfArgs &a, const EnvRegs &S, const uint32_t Rv, const bool lane_env,
-                                              const uint32_t ek, const bool do_update)
+__device__ __forceinline__ uint4 group_phase_c(const WfArgs &a, const EnvRegs &S, const uint32_t Rv, const bool lane_env,
+                                               const uint32_t ek, const bool do_update)
 {
     constexpr int CELLS = W * H;
     uint32_t ax = S.ax, ay = S.ay, fl = S.fl, episode = S.episode, tick = S.tick;
@@ -166,6 +170,7 @@ __device__ __forceinline__ void group_phase_c(const WfArgs &a, const EnvRegs &S,
             if (a.done) a.done[ek] = (uint8_t)done;
         }
     }
+    return make_uint4(ax | (ay << 16), fl, episode, tick);
 }
 
 // SHARED = false: every wave runs phases A, B, C for its own group of G environments.

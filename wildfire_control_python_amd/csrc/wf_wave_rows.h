@@ -256,7 +256,19 @@ __device__ __forceinline__ void set_progress_prio(uint32_t done, uint32_t total)
 #define WF_ROWS_WPB 4
 #endif
 // MULTI = true: an n_steps call served by one launch (the step loop below); false: exactly one step, the loop folds away.
-template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE>
+// RES (with MULTI): RESIDENT step loop.  The wave copies its environments' cells into an LDS mirror once, runs all its
+// steps on the mirror (the agent phase reads and patches bytes there, the tick loads and stores row pieces there, the
+// records travel from phase C to the next phase A through LDS) and writes the cells back once at the end.  Per step
+// that leaves stores of reward / done / record and one action load - no round trip to L2 on the critical path, where
+// the plain step loop has four (record, type bytes, cells, cells again after the agent's byte stores).  MEASURED, and
+// therefore opt-in (WF_RESIDENT=1): it is no faster - 4 096 x 10x10 x 16 ticks 42.1 us against 42.5 through L2 (and 37.7 on
+// the one-environment-per-wave kernel), 8 192: 48.3 against 49.8, 65 536 x 14x14: 15.6 against 15.0 us per step.  A wave of
+// the step loop is bound by instruction issue along its own dependency chain (~450 instructions per step at 2
+// environments per wave, 6 cycles each with two waves per SIMD), not by the L2 round trips the mirror removes.
+#ifndef WF_RES_MAXG
+#define WF_RES_MAXG 8        // environments per wave of the resident loop (LDS mirror: WF_RES_MAXG x W x H x 4 bytes per wave)
+#endif
+template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE, bool RES = false>
 // Waves per SIMD: minimum = maximum = 8.  (A minimum of 7 gives the register allocator 94 scalar registers instead of
 // 80 and removes a third of the scalar spills to VGPR lanes, and the compiler still reports 8 waves per SIMD - but a
 // wave's 94 SGPRs are allocated as 112, 800 / 112 = 7: tools/wave_timeline.py showed exactly one workgroup in eight
@@ -291,6 +303,18 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     // n_steps > 1: the wave simply steps its environments again (each wave owns its environments, so nothing has
     // to be synchronised across waves); this spares a kernel boundary - 2.8 us of dispatch - per step and launch.
     static_assert(!(SHARED && MULTI), "the workgroup-shared variant steps once");
+    static_assert(!RES || (MULTI && WF_STORE_AUX == 0), "the resident loop is a step loop with plain stores");
+    // ---- RES: the wave's cells -> LDS mirror; from here on "the planes" of this wave are the mirror
+    extern __shared__ uint32_t sMirror[];                    // RES: [waves per workgroup][G * CELLS], sized by the launch
+    uint32_t *mirror = sMirror + (RES ? wv * G * (uint32_t)CELLS : 0u);
+    uint32_t *planes_wave = nullptr;                         // (generic pointer such that planes_wave + e * CELLS is env e's mirror)
+    if constexpr (RES) {
+        const uint32_t *src = a0.planes + (size_t)e0 * CELLS;
+        for (uint32_t i = lane; i < ng * (uint32_t)CELLS; i += 64u) mirror[i] = src[i];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        planes_wave = mirror - (size_t)e0 * CELLS;
+    }
 #if WF_PROGRESS_PRIO
     if constexpr (!SHARED && !MULTI) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -308,6 +332,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         if (a.actions) a.actions += so;
         if (a.reward) a.reward += so;
         if (a.done) a.done += so;
+        if constexpr (RES) a.planes = planes_wave;
         a.update_mask = a0.update_mask >> st;
         if (st + 1u < nst) a.obs = nullptr;                             // the observation of the final state only
         if (st) {
@@ -321,7 +346,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     const bool do_update = (a.update_mask & 1ull) != 0;
     char *planes_b = reinterpret_cast<char *>(a.planes);
     // (this launch's planes; 32-bit byte offsets - wf_create keeps a context's planes below 4 GiB)
-    const __amdgpu_buffer_rsrc_t planes_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.planes, 0, (int)(batch * ENV_BYTES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t planes_rsrc = __builtin_amdgcn_make_buffer_rsrc(a0.planes, 0, (int)(batch * ENV_BYTES), 0x00020000);   // (WF_STORE_AUX builds only)
     __shared__ uint32_t sS[7][SHARED ? 64 : 32 * WF_ROWS_WPB];   // ax|ay<<16, fl, episode, tick, Pv, Rv, counter
     enum { S_POS = 0, S_FL = 1, S_EP = 2, S_TICK = 3, S_P = 4, S_R = 5, S_CNT = 6 };
 
@@ -330,7 +355,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     const uint32_t ek = A0 + (lane_env ? lane : 0u);
     const uint32_t ai = SHARED ? lane : gi0 + (lane_env ? lane : 0u);   // LDS slot of this env-lane
     if (!SHARED || wv == 0) {
-        const EnvRegs S0 = group_phase_a<W, H, 8, RARE>(a, lane_env, ek, do_update);
+        EnvRegs S0;
+        if (RES && st > 0u) {       // the record phase C of the last step left in LDS
+            const uint4 pre = make_uint4(sS[S_POS][ai], sS[S_FL][ai], sS[S_EP][ai], sS[S_TICK][ai]);
+            S0 = group_phase_a<W, H, 8, RARE, true>(a, lane_env, ek, do_update, pre);
+        } else {
+            S0 = group_phase_a<W, H, 8, RARE>(a, lane_env, ek, do_update);
+        }
         if (lane_env) {
             sS[S_POS][ai] = S0.ax | (S0.ay << 16);
             sS[S_FL][ai] = S0.fl;
@@ -621,7 +652,16 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         S1.tick = sS[S_TICK][ai];
         S1.Pv = sS[S_P][ai];
         const uint32_t Rv = sS[S_R][ai];
-        group_phase_c<W, H, 8>(a, S1, Rv, lane_env, ek, do_update);
+        const uint4 rec = group_phase_c<W, H, 8>(a, S1, Rv, lane_env, ek, do_update);
+        if constexpr (RES) {
+            if (lane_env) {
+                sS[S_POS][ai] = rec.x;
+                sS[S_FL][ai] = rec.y;
+                sS[S_EP][ai] = rec.z;
+                sS[S_TICK][ai] = rec.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
     }
 #ifdef WF_WAVE_TIMING
     if (a0.mask && lane == 0) {      // (the reset mask pointer is unused by step launches: the timing buffer rides on it)
@@ -637,4 +677,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
     }
 #endif
     }   // steps
+    if constexpr (RES) {            // the mirror -> the planes
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t *dst = a0.planes + (size_t)e0 * CELLS;
+        for (uint32_t i = lane; i < ng * (uint32_t)CELLS; i += 64u) dst[i] = mirror[i];
+    }
 }
