@@ -454,9 +454,20 @@ def main():
         for s in range(1, 30):
             env.step_many(a_np[s])
         th = time.perf_counter() - th
+        # the same with the pinned buffers the library lends (wf_host_staging): no host copies of actions / reward / done
+        l_act, _, _ = env.host_staging(1)
+        l_act[0] = a_np[0]
+        env.step_many(l_act, borrow=True)
+        tl = time.perf_counter()
+        for s in range(1, 30):
+            l_act[0] = a_np[s]
+            env.step_many(l_act, borrow=True)
+        tl = time.perf_counter() - tl
         host_api = {"cell_updates_per_s": cells * 29 / th, "us_per_step": th / 29 * 1e6,
-                    "note": "wf_step(): numpy in / out, PCIe and host synchronisation included; at this size actions / reward / done travel "
-                            "through device mirrors and one copy kernel each way (small batches: the kernels read and write pinned host memory)"}
+                    "lent_buffers_us_per_step": tl / 29 * 1e6, "lent_buffers_cell_updates_per_s": cells * 29 / tl,
+                    "note": "wf_step(): numpy in / out, PCIe and host synchronisation included (the kernels read actions from and write "
+                            "reward / done to pinned host memory); lent_buffers = the same call on the pinned buffers wf_host_staging lends: "
+                            "no host copies.  Never `value`: large batches belong on the device API"}
 
     # extra: the single-environment drop-in the reference's learners call (ForestFire.step: numpy in / out, the host view
     # refreshed after every step), against the reference's own Python step timed in the build container
@@ -497,8 +508,8 @@ def main():
             "c4": dict(S=256, B=1024, noop=True, ppm=10000, steps=200, warmup=20),
             "c5_shard": dict(S=14, B=125000, noop=False, env_id0=875000, steps=400, warmup=40),
             "hbm_1m": dict(S=14, B=1048576, noop=False, steps=120, warmup=20),
-            # informational (no BASELINE config): the reference's off-by-default wind option at the headline size (generic
-            # kernel family), and a mid-size grid (tiled family, strips packed four per wave)
+            # informational (no BASELINE config): the reference's off-by-default wind option at the headline size (the wave
+            # family's group-layout kernel with per-direction heat counts), and a mid-size grid (tiled family, four strips per wave)
             "c3_wind": dict(S=14, B=65536, noop=False, steps=200, warmup=20, wind="random"),
             "mid_64": dict(S=64, B=4096, noop=False, steps=200, warmup=20),
         }

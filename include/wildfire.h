@@ -122,8 +122,9 @@ typedef struct wf_params {
      * then depends on the direction burning cell -> heated cell, wind_speed * heat * (angle + 1)^-1
      * (environment.py:260-287), a cell ignites when the float64 sum of its addends exceeds `threshold`, and the
      * state gains a per-direction count of addends for every grass cell (wf_wind_counts_*); plane 2 then only
-     * records how a cell was ignited (0 / WF_HEAT_FORCED / WF_HEAT_IGNITED).  Served by the thread-per-cell
-     * kernel family for every grid shape. */
+     * records how a cell was ignited (0 / WF_HEAT_FORCED / WF_HEAT_IGNITED).  Served by a wind instantiation of the
+     * register-resident group-layout kernel for the shapes the wave family serves (10x10, 14x14, ...), by the generic
+     * kernel family for every other grid shape. */
     int32_t wind_mode;         /* WF_WIND_*                                             */
     int32_t wind_code;         /* WF_WIND_FIXED: the code of every environment          */
     double  wind_speed[4];     /* speeds a code's index selects; {0, 0.7, 0.85} for "random" (environment.py:189) */
@@ -191,6 +192,13 @@ int wf_step(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mas
             double *reward, uint8_t *done);
 int wf_step_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
                    double *d_reward, uint8_t *d_done);
+
+/* Pinned host buffers the library lends for wf_step / wf_step_obs calls of up to n_steps steps: actions int8
+ * (n_steps, batch), reward float64 (n_steps, batch), done uint8 (n_steps, batch).  A call that is handed these very
+ * pointers reads and writes them in place - no host copy in either direction (at 65 536 environments the copies of a
+ * step's reward and done are 590 KB, about as long as the step itself).  The pointers stay valid until a call with a
+ * larger n_steps, or wf_destroy; their contents until the next wf_step*.  Any of the three may be NULL. */
+int wf_host_staging(wf_ctx *ctx, int n_steps, int8_t **actions, double **reward, uint8_t **done);
 
 /* The same steps, and World.get_state() of the resulting state written in the same launch
  * (the grid is in registers anyway): obs int8 (batch, W, H, 3).  This is what

@@ -166,3 +166,39 @@ def test_oracle_reproduces_the_published_baseline_reward(size):
     tol = baseline_tolerance(total.std(), B)
     assert abs(total.mean() - REFERENCE_BASELINE_MEAN[size]) < tol, (total.mean(), tol)
     assert 0.01 < died.mean() < 0.15 and 60 < steps.mean() < 200
+
+
+def test_search_model_reaches_exactly_what_the_reference_astar_finds():
+    """oracle/_ref/astar.so is the reference's OWN native helper, compiled from pyastar/astar.cpp where it lies
+    (oracle/Makefile).  On random maps of passable / blocked cells, `SearchState.reaches` (tests/ref_reward_model.py) must say
+    "route" exactly when the reference's A* does - blocked start cells (their weight is never charged), blocked goals,
+    start == goal and all."""
+    import ctypes
+    import os
+    from tests.ref_reward_model import SearchState
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "astar.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/astar.so not built (needs /root/reference)")
+    lib = ctypes.cdll.LoadLibrary(so)
+    f32 = np.ctypeslib.ndpointer(dtype=np.float32, ndim=1, flags="C_CONTIGUOUS")
+    i32 = np.ctypeslib.ndpointer(dtype=np.int32, ndim=1, flags="C_CONTIGUOUS")
+    lib.astar.restype = ctypes.c_bool
+    lib.astar.argtypes = [f32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_bool, i32]
+    rng = np.random.default_rng(7)
+    checked = routes = 0
+    for size in (10, 14):
+        for _ in range(60):
+            blocked = rng.random((size, size)) < rng.choice([0.2, 0.35, 0.5])         # [y, x]
+            types = np.where(blocked, 3, 0)
+            st = SearchState(types)
+            # the reference hands astar the fire_mobility layer indexed [x, y] (environment.py:353-356)
+            weights = np.where(blocked.T, np.inf, 1.0).astype(np.float32)              # [x, y]
+            for _ in range(40):
+                sx, sy, gx, gy = (int(v) for v in rng.integers(0, size, size=4))
+                paths = np.full(size * size, -1, dtype=np.int32)
+                found = bool(lib.astar(weights.ravel(), size, size, sx * size + sy, gx * size + gy, False, paths))
+                found = found and (sx, sy) != (gx, gy)            # pyastar.py:52-64: an empty path for start == goal
+                assert st.reaches((sx, sy), (gx, gy)) == found, (size, sx, sy, gx, gy)
+                checked += 1
+                routes += found
+    assert checked == 4800 and 500 < routes < 4300

@@ -61,6 +61,7 @@ class BatchedForestFire:
         self.n_actions = self.METADATA["n_actions"]
         self.seed = int(seed)
         self._reset_count = 0
+        self._staging = None
 
         # World.reset, environment.py:187-193.  Wind vector (0,0): every heat addend is the same quantum and the rule
         # is an integer count (ignite_count).  A vector with a direction - fixed, or drawn per episode with "random" -
@@ -314,10 +315,24 @@ class BatchedForestFire:
                 md["a_speed_iter"] = md["a_speed"]
         return m
 
-    def step_many(self, actions=None, n_steps=None):
-        """n_steps fused ForestFire.step() calls in ONE kernel launch (the grid stays in
+    def host_staging(self, n_steps=1):
+        """(actions int8, reward float64, done uint8) numpy VIEWS, each (n_steps, batch), of the pinned host buffers the
+        library lends (wf_host_staging): step_many(..., borrow=True) works on them in place, without host copies."""
+        n_steps = int(n_steps)
+        if self._staging is None or self._staging[0] != n_steps:
+            pa, pr, pd = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            self._ck(self._lib.wf_host_staging(self._h, n_steps, ctypes.byref(pa), ctypes.byref(pr), ctypes.byref(pd)), "wf_host_staging")
+            shape = (n_steps, self.batch)
+            view = lambda p, ct, dt: np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ct)), shape=shape).view(dt)
+            self._staging = (n_steps, view(pa, ctypes.c_int8, np.int8), view(pr, ctypes.c_double, np.float64), view(pd, ctypes.c_uint8, np.uint8))
+        return self._staging[1:]
+
+    def step_many(self, actions=None, n_steps=None, borrow=False):
+        """n_steps ForestFire.step() calls in one API call (small batches: ONE kernel launch, the grid stays in
         registers between ticks).  actions int8 (n_steps, batch) or None for no-ops.
-        Returns (reward float64 (n_steps,batch), done bool (n_steps,batch))."""
+        Returns (reward float64 (n_steps,batch), done bool (n_steps,batch)).
+        borrow=True: reward and done (uint8) are views of the library's pinned buffers, valid until the next step call -
+        no host copies (at 65 536 environments they cost as much as the step); actions may be the lent action view."""
         if actions is not None:
             actions = np.ascontiguousarray(actions, dtype=np.int8)
             if actions.ndim == 1:
@@ -325,9 +340,15 @@ class BatchedForestFire:
             assert actions.shape[1] == self.batch
             n_steps = actions.shape[0]
         n_steps = int(n_steps or 1)
+        mask = self._update_mask(n_steps)
+        if self._staging is not None and n_steps > self._staging[0]:
+            self._staging = None                      # a longer call re-allocates the lent buffers: the old views dangle
+        if borrow:
+            _, reward, done = self.host_staging(n_steps)
+            self._ck(self._lib.wf_step(self._h, N.ptr(actions), n_steps, ctypes.c_uint64(mask), N.ptr(reward), N.ptr(done)), "wf_step")
+            return reward, done
         reward = np.empty((n_steps, self.batch), dtype=np.float64)
         done = np.empty((n_steps, self.batch), dtype=np.uint8)
-        mask = self._update_mask(n_steps)
         self._ck(self._lib.wf_step(self._h, N.ptr(actions), n_steps, ctypes.c_uint64(mask),
                                    N.ptr(reward), N.ptr(done)), "wf_step")
         return reward, done.astype(bool)

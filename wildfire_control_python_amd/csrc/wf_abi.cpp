@@ -47,8 +47,6 @@ struct wf_ctx {
     // directly over PCIe.  No DMA operation per array and step - at 20 us per step those, not the bytes, were the cost:
     // 16 against 49-119 us per wf_step of one environment, 19 against 56 at 4 096, 62 against 117 at 65 536.
     int8_t *d_actions = nullptr;
-    double *d_reward = nullptr;
-    uint8_t *d_done = nullptr;
     int8_t *h_obs = nullptr;          // small observations the same way (up to WF_ZC_OBS_MAX bytes; larger ones by DMA)
     uint8_t *h_dl = nullptr;          // wf_download of a small context: planes + records through one copy kernel
     size_t h_dl_bytes = 0;
@@ -58,10 +56,8 @@ struct wf_ctx {
     uint8_t *d_mode = nullptr;        // big-grid families: per-env mode of the current step
     uint32_t *d_acc = nullptr;        // big-grid families: per-env reduction words
     int staged_steps = 0;
-    // Large batches (>= WF_HOST_STAGE_MIN actions per call): device mirrors of actions / reward+done.  A copy kernel
-    // brings the actions over before the step and takes reward and done back after it with wide coalesced PCIe
-    // accesses, instead of every wave of the step kernel paying a PCIe round trip in its agent phases
-    // (65 536 x 14x14: wf_step 97 -> see DESIGN.md us).  Pinned `d_reward` and `d_done` are then ONE block.
+    // reward and done of the host-buffer entry points: ONE pinned block (p_out), lent to callers by wf_host_staging.
+    // (v_actions / v_out: device mirrors of the WF_HOST_STAGE_MIN experiment, see wf_step_obs.)
     int8_t *v_actions = nullptr;
     uint8_t *v_out = nullptr;          // [n doubles of reward][n bytes of done]
     uint8_t *p_out = nullptr;          // pinned host block of the same layout
@@ -342,14 +338,10 @@ int ensure_staging(wf_ctx *c, int n_steps)
     if (n_steps <= c->staged_steps) return WF_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->d_actions) (void)hipHostFree(c->d_actions);
-    if (c->d_reward) (void)hipHostFree(c->d_reward);
-    if (c->d_done) (void)hipHostFree(c->d_done);
-    c->d_actions = nullptr; c->d_reward = nullptr; c->d_done = nullptr;
+    c->d_actions = nullptr;
     c->staged_steps = 0;
     const size_t n = (size_t)n_steps * (size_t)c->batch;
     HIP_TRY(c, hipHostMalloc((void **)&c->d_actions, (n + 15) & ~(size_t)15, hipHostMallocDefault));   // (copied in whole dwords)
-    HIP_TRY(c, hipHostMalloc((void **)&c->d_reward, n * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void **)&c->d_done, n, hipHostMallocDefault));
     c->staged_steps = n_steps;
     return WF_OK;
 }
@@ -382,7 +374,8 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
                                               : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps)));
     WfKnobs kn = c->knobs;
     kn.multi_rows = in_kernel ? 1 : 0;
-    const bool each = n_steps > 1 && splits(c, 1) && !in_kernel;
+    // (wind with a direction has a single-step kernel only: n single-step launches whatever the batch)
+    const bool each = n_steps > 1 && ((splits(c, 1) && !in_kernel) || c->p.wind_mode != WF_WIND_CALM);
     const int n_launch = each ? n_steps : 1;
     const size_t cells = (size_t)c->H * c->W;
     for (int st = 0; st < n_launch; ++st) {
@@ -419,6 +412,7 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
             ai.planes_out = ai.planes;
             ai.envs = a.envs + lo;
             ai.reach = a.reach + (size_t)lo * 4;
+            if (a.wind_cnt) ai.wind_cnt = a.wind_cnt + (size_t)lo * cells;
             if (a.actions) ai.actions = a.actions + lo;
             if (a.reward) ai.reward = a.reward + lo;
             if (a.done) ai.done = a.done + lo;
@@ -519,12 +513,14 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
     if (p) pp = *p; else wf_default_params(&pp);
     if (!params_ok(&pp)) return WF_ERR_ARG;
     if (wind_params_status(&pp) != WF_OK) return WF_ERR_UNSUPPORTED;
-    // wind with a direction is served by the thread-per-cell family, whatever the shape
+    // wind with a direction: the wave family's group-layout kernel for the shapes it serves (round 3), the generic family
+    // for every other shape
     // (WF_FAMILY=cells / tiled, experiments and tests: the generic family for a shape another family would serve, the
     // tiled family for a small grid)
     WfKnobs kn0;
     wf_read_knobs(&kn0);
-    WfFamily fam = (pp.wind_mode != WF_WIND_CALM || kn0.family == 1) ? WF_FAM_CELLS : wf_pick_family(H, W);
+    WfFamily fam = kn0.family == 1 ? WF_FAM_CELLS : wf_pick_family(H, W);
+    if (pp.wind_mode != WF_WIND_CALM && fam != WF_FAM_WAVE) fam = WF_FAM_CELLS;
     if (kn0.family == 2 && fam == WF_FAM_CELLS && pp.wind_mode == WF_WIND_CALM && wf_tiled_serves(H, W)) fam = WF_FAM_TILED;
     if (fam == WF_FAM_NONE) return WF_ERR_UNSUPPORTED;
     // the wave kernels address the planes with 32-bit byte offsets
@@ -628,7 +624,7 @@ int wf_destroy(wf_ctx *c)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
-    void *pinned[] = { c->d_actions, c->d_reward, c->d_done, c->h_obs, c->h_dl, c->p_out };
+    void *pinned[] = { c->d_actions, c->h_obs, c->h_dl, c->p_out };
     for (void *b : pinned)
         if (b) (void)hipHostFree(b);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo, c->wind_cnt,
@@ -862,11 +858,35 @@ int wf_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
     return wf_step_obs(c, actions, n_steps, update_mask, reward, done, nullptr);
 }
 
+// Pinned staging of the host-buffer entry points for calls of up to n_steps steps: ONE pinned block laid out
+// [n doubles of reward][n bytes of done] (p_out) and the pinned action block (d_actions), n = n_steps x batch.
+int ensure_host_staging(wf_ctx *c, int n_steps)
+{
+    int rc = ensure_staging(c, n_steps);
+    if (rc != WF_OK) return rc;
+    return ensure_mirrors(c, (size_t)c->staged_steps * (size_t)c->batch);
+}
+
+int wf_host_staging(wf_ctx *c, int n_steps, int8_t **actions, double **reward, uint8_t **done)
+{
+    if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    JOIN(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = ensure_host_staging(c, n_steps);
+    if (rc != WF_OK) return rc;
+    const size_t n = (size_t)n_steps * (size_t)c->batch;
+    if (actions) *actions = c->d_actions;
+    if (reward) *reward = reinterpret_cast<double *>(c->p_out);
+    if (done) *done = c->p_out + n * sizeof(double);
+    return WF_OK;
+}
+
 int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
                 double *reward, uint8_t *done, int8_t *obs)
 {
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
-    int rc = ensure_staging(c, n_steps);
+    int rc = ensure_host_staging(c, n_steps);
     if (rc != WF_OK) return rc;
     const size_t n = (size_t)n_steps * (size_t)c->batch;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -876,40 +896,43 @@ int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_m
     if (zc_obs && !c->h_obs) HIP_TRY(c, hipHostMalloc((void **)&c->h_obs, nobs, hipHostMallocDefault));
     if (obs && !zc_obs && !c->d_obs) HIP_TRY(c, hipMalloc((void **)&c->d_obs, nobs));
     int8_t *obs_dst = !obs ? nullptr : zc_obs ? c->h_obs : c->d_obs;
-    const size_t stage_min = c->knobs.host_stage_min > 0 ? (size_t)c->knobs.host_stage_min : (size_t)16384;
-    if (n >= stage_min) {
-        // large batch: actions in and reward / done out through device mirrors and one copy kernel each way
-        if ((rc = ensure_mirrors(c, n)) != WF_OK) return rc;
-        if (actions) {
-            memcpy(c->d_actions, actions, n);
-            HIP_TRY(c, wf_launch_copy_words(c->d_actions, c->v_actions, (n + 3) & ~(size_t)3, c->stream));
-        }
+    // pinned host views of this call: reward / done inside the one pinned block.  A caller that passes the pointers
+    // wf_host_staging() lent it spares the host copies (590 KB per step at 65 536 environments: ~45 us of memcpy).
+    double *p_reward = reinterpret_cast<double *>(c->p_out);
+    uint8_t *p_done = c->p_out + n * sizeof(double);
+    if (actions && actions != c->d_actions) memcpy(c->d_actions, actions, n);
+    // Experiment (WF_HOST_STAGE_MIN=n, off by default): calls of at least n actions go through DEVICE MIRRORS - bit 0 of
+    // WF_HOST_STAGE_MODE: the actions come over with one coalesced copy kernel before the step; bit 1: reward / done
+    // leave through a mirror and one copy kernel after it - instead of the step kernel reading and writing pinned host
+    // memory itself.  Measured at 65 536 x 14x14 (us per wf_step, caller-owned arrays / lent buffers): no mirrors
+    // 87 / 70, actions 74 lent, results 97 / 77, both 95 / 75.  The extra launches and the join cost more than the
+    // kernel's own PCIe accesses; what does help is lending the pinned buffers (wf_host_staging: no host copies).
+    const size_t stage_min = c->knobs.host_stage_min > 0 ? (size_t)c->knobs.host_stage_min : ~(size_t)0;
+    const int stage_mode = n >= stage_min ? (c->knobs.host_stage_mode > 0 ? c->knobs.host_stage_mode : 3) : 0;
+    if (stage_mode) {
+        const bool in_m = (stage_mode & 1) != 0, out_m = (stage_mode & 2) != 0;
+        if (actions && in_m) HIP_TRY(c, wf_launch_copy_words(c->d_actions, c->v_actions, (n + 3) & ~(size_t)3, c->stream));
         double *v_reward = reinterpret_cast<double *>(c->v_out);
         uint8_t *v_done = c->v_out + n * sizeof(double);
-        rc = wf_step_obs_device(c, actions ? c->v_actions : nullptr, n_steps, update_mask, reward ? v_reward : nullptr, done ? v_done : nullptr, obs_dst);
+        rc = wf_step_obs_device(c, !actions ? nullptr : in_m ? c->v_actions : c->d_actions, n_steps, update_mask,
+                                !reward ? nullptr : out_m ? v_reward : p_reward, !done ? nullptr : out_m ? v_done : p_done, obs_dst);
         if (rc != WF_OK) return rc;
         JOIN(c);
-        if (reward || done) {
+        if ((reward || done) && out_m) {
             const size_t lo = reward ? 0 : n * sizeof(double), hi = done ? n * 9 : n * sizeof(double);
             HIP_TRY(c, wf_launch_copy_words(c->v_out + lo, c->p_out + lo, (hi - lo + 3) & ~(size_t)3, c->stream));
         }
-        if (obs && !zc_obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (zc_obs) memcpy(obs, c->h_obs, nobs);
-        if (reward) memcpy(reward, c->p_out, n * sizeof(double));
-        if (done) memcpy(done, c->p_out + n * sizeof(double), n);
-        return WF_OK;
+    } else {
+        // small batch: the kernels read the actions from and write reward / done to pinned host memory themselves
+        rc = wf_step_obs_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask, reward ? p_reward : nullptr, done ? p_done : nullptr, obs_dst);
+        if (rc != WF_OK) return rc;
+        JOIN(c);
     }
-    if (actions) memcpy(c->d_actions, actions, n);          // pinned: the kernels read it in place
-    rc = wf_step_obs_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask,
-                            reward ? c->d_reward : nullptr, done ? c->d_done : nullptr, obs_dst);
-    if (rc != WF_OK) return rc;
-    JOIN(c);
     if (obs && !zc_obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (zc_obs) memcpy(obs, c->h_obs, nobs);
-    if (reward) memcpy(reward, c->d_reward, n * sizeof(double));
-    if (done) memcpy(done, c->d_done, n);
+    if (reward && reward != p_reward) memcpy(reward, p_reward, n * sizeof(double));
+    if (done && done != p_done) memcpy(done, p_done, n);
     return WF_OK;
 }
 
@@ -986,7 +1009,7 @@ const char *wf_step_kernel_name(const wf_ctx *c)
 const char *wf_call_kernel_name(const wf_ctx *c, int n_steps)
 {
     if (!c || n_steps < 1) return "none";
-    if (n_steps == 1 || c->fam != WF_FAM_WAVE) return wf_step_kernel_name(c);
+    if (n_steps == 1 || c->fam != WF_FAM_WAVE || c->p.wind_mode != WF_WIND_CALM) return wf_step_kernel_name(c);
     const bool sp = splits(c, 1);
     const bool in_kernel = sp ? multi_rows_call(c, n_steps) : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps));
     if (!in_kernel) return sp ? wf_step_kernel_name(c) : "wf_step_wave (fused ticks, one environment per wave)";
@@ -1003,8 +1026,10 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
 {
     if (!c || n_steps < 1) return 0;
     if (c->fam != WF_FAM_WAVE) return n_steps * (splits_big(c) ? c->n_parts : 1);      // launch sequences
-    if (!splits(c, 1)) return n_steps == 1 ? 1 : 1;                                     // one (fused) launch
-    if (n_steps == 1) return c->n_parts;
+    const int per_step = splits(c, 1) ? c->n_parts : 1;
+    if (n_steps == 1) return per_step;
+    if (c->p.wind_mode != WF_WIND_CALM) return per_step * n_steps;                      // wind: single-step launches only
+    if (!splits(c, 1)) return 1;                                                        // one (fused) launch
     return multi_rows_call(c, n_steps) ? c->n_parts : c->n_parts * n_steps;
 }
 

@@ -74,7 +74,8 @@ struct WfKnobs {
     int family;       // WF_FAMILY=cells (1) / tiled (2): kernel family override, honoured by wf_create only
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
-    int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = 16 384)
+    int host_stage_mode; // WF_HOST_STAGE_MODE: 1 actions through a device mirror, 2 reward / done, 3 both (default of the experiment)
+    int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
     int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop

@@ -157,6 +157,14 @@ __device__ __forceinline__ void reset_regs(const WfCold *cold_g, u64 seed, uint3
     s.ax = sx;
     s.ay = sy;
     s.fl = WF_F_ALIVE | WF_F_VISIBLE | WF_F_DIGGING | WF_F_RUNNING | (rivers ? 0u : (uint32_t)WF_F_REACH_VALID) | (onborder ? WF_F_BORDER : 0u);
+    // World.reset :187-193: the episode's wind (wind with a direction only; the code rides in the upper half of the flags word)
+    const int32_t wmode = cold->p.wind_mode;
+    if (wmode != WF_WIND_CALM) {
+        uint32_t code = (uint32_t)cold->p.wind_code;
+        if (wmode == WF_WIND_RANDOM)                                  // :189-190, three uniform draws
+            code = WF_WIND_CODE((int)below(key.draw(3), 3u) - 1, (int)below(key.draw(4), 3u) - 1, below(key.draw(2), 3u));
+        s.fl |= code << 16;
+    }
     s.episode += 1;
     s.tick = 0;
 }
@@ -274,8 +282,10 @@ __global__ __launch_bounds__(256) void wf_reset_wave(const WfArgs a)
         for (int j = 0; j < 4; ++j)
             r[j] = t[j] | (u[j] << 8) | (h[j] << 16) |
                    ((lane == (qa >> 2) && (qa & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
-        if (lane < (uint32_t)LANES)
+        if (lane < (uint32_t)LANES) {
             reinterpret_cast<uint4 *>(a.planes + (size_t)e * CELLS)[lane] = make_uint4(r[0], r[1], r[2], r[3]);
+            if (a.wind_cnt) reinterpret_cast<uint4 *>(a.wind_cnt + (size_t)e * CELLS)[lane] = make_uint4(0, 0, 0, 0);   // no heat received yet
+        }
         if (lane == 0)
             *reinterpret_cast<uint4 *>(&a.envs[e]) = make_uint4(s.ax | (s.ay << 16), s.fl, s.episode, s.tick);
     }
@@ -465,8 +475,10 @@ StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
         if (a.n_steps > 1 && p.G < EPW0) p.G = EPW0;
     }
     // (the workgroup-shared experiment exists for the reference's default options only)
-    const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096 && !(a.hot_flags & WF_HOT_RARE);
+    const bool wind = (a.hot_flags & WF_HOT_WIND) != 0;      // wind with a direction: the group layout's WIND instantiation
+    const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096 && !(a.hot_flags & WF_HOT_RARE) && !wind;
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
+    if (wind) return p;
     if constexpr (HasRows<W, H>::value) {
         constexpr int EPW = RG<W, H, HasRows<W, H>::S>::EPW;
         // (wf_pick_group_for keeps G <= 16 for these shapes; an override beyond that needs WF_ROWS=1 to stay on rows)
@@ -488,6 +500,7 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
     if (reset)
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.n_steps > 1 && !k.multi_rows) {
+        if (a.hot_flags & WF_HOT_WIND) return hipErrorInvalidValue;     // (wind: the host issues n single-step launches)
         if (rare) hipLaunchKernelGGL((wf_step_wave<W, H, true, true>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wf_step_wave<W, H, true, false>), dim3(blocks), dim3(256), 0, s, a);
     } else {
@@ -517,8 +530,11 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
                 hipLaunchKernelGGL((wf_step_rows<W, H, S, true, false, false>), dim3((a.batch + per_wg - 1) / per_wg), dim3(64 * nw), 0, s, g);
             }
         }
-        if (p.kind == STEP_GROUP && !rare) hipLaunchKernelGGL((wf_step_group<W, H, false, false>), grid_private, dim3(256), 0, s, g);
-        if (p.kind == STEP_GROUP && rare) hipLaunchKernelGGL((wf_step_group<W, H, false, true>), grid_private, dim3(256), 0, s, g);
+        const bool wind = (a.hot_flags & WF_HOT_WIND) != 0;
+        if (p.kind == STEP_GROUP && !rare && !wind) hipLaunchKernelGGL((wf_step_group<W, H, false, false>), grid_private, dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP && rare && !wind) hipLaunchKernelGGL((wf_step_group<W, H, false, true>), grid_private, dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP && !rare && wind) hipLaunchKernelGGL((wf_step_group<W, H, false, false, true>), grid_private, dim3(256), 0, s, g);
+        if (p.kind == STEP_GROUP && rare && wind) hipLaunchKernelGGL((wf_step_group<W, H, false, true, true>), grid_private, dim3(256), 0, s, g);
         if (p.kind == STEP_GROUP_SHARED) hipLaunchKernelGGL((wf_step_group<W, H, true, false>), grid_shared, block_shared, 0, s, g);
     }
     return hipGetLastError();
@@ -569,6 +585,7 @@ void wf_read_knobs(WfKnobs *k)
     k->no_resident = !set("WF_RESIDENT");     // opt-in experiment (measured: no gain, profiles/r03_c2_variants.txt)
     k->graph = set("WF_GRAPH");
     k->host_stage_min = num("WF_HOST_STAGE_MIN", 0);
+    k->host_stage_mode = num("WF_HOST_STAGE_MODE", 0);
     k->multi_rows = 0;
 }
 
@@ -617,7 +634,7 @@ bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int 
 {
     // (below 4 096 environments per launch the one-environment-per-wave kernel has more waves to hide its latency with:
     // 4 096 x 10x10 x 16 ticks 37.7 us against 42.1 on the step loop with 2 environments per wave)
-    if (fam != WF_FAM_WAVE || a.step_stride <= 0 || a.batch < 4096 || k.no_multi) return false;
+    if (fam != WF_FAM_WAVE || a.step_stride <= 0 || a.batch < 4096 || k.no_multi || (a.hot_flags & WF_HOT_WIND)) return false;
     StepPlan p = { 0, -1 };
 #define X(w, h) if (a.W == w && a.H == h) p = plan_single<w, h>(a, k, num_cus);
     WF_WAVE_SHAPES(X)
@@ -638,6 +655,7 @@ const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &
 #undef X
     if (p.kind < 0) return "none";
     if (p.kind >= STEP_ROWS) snprintf(buf, sizeof buf, "wf_step_rows<%d,%d,%d,%s>", a.W, a.H, S, p.kind == STEP_ROWS_SHARED ? "true" : "false");
+    else if (a.hot_flags & WF_HOT_WIND) snprintf(buf, sizeof buf, "wf_step_group<%d,%d,wind>", a.W, a.H);
     else snprintf(buf, sizeof buf, "wf_step_group<%d,%d,%s>", a.W, a.H, p.kind == STEP_GROUP_SHARED ? "true" : "false");
     return buf;
 }

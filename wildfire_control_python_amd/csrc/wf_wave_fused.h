@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, WF_LB) void wf_step_wave(const WfArgs a)
                 if (a.actions) act_pref = (uint32_t)(uint8_t)a.actions[en];
             }
         }
-        uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu, episode = ev.z, tick = ev.w;
+        // (fl: the record's whole second word; its upper half - the wind code of wind contexts, unused here - rides along)
+        uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y, episode = ev.z, tick = ev.w;
         // The compiler knows a load from a wave-uniform address is wave-uniform and would move
         // these to scalar registers (and all the flag logic below onto the scalar unit with
         // them).  Opaque VGPR constraints keep them - deliberately - on the vector side.

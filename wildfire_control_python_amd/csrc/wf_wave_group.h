@@ -41,7 +41,9 @@ __device__ __forceinline__ EnvRegs group_phase_a(const WfArgs &a, const bool lan
     uint4 ev = pre;
     if constexpr (!PRE) ev = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.envs) + ek * 16u);
     const uint32_t act = a.actions ? (uint32_t)(uint8_t)a.actions[ek] : 0xffu;
-    uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y & 0xffffu, episode = ev.z, tick = ev.w;
+    // fl: the record's whole second word = flags | wind code << 16.  The flag logic only ever looks at and changes the
+    // low bits, so the environment's wind code (wind with a direction; 0 otherwise) rides along into phase C's record.
+    uint32_t ax = ev.x & 0xffffu, ay = ev.x >> 16, fl = ev.y, episode = ev.z, tick = ev.w;
     const uint32_t running = (fl >> 4) & 1u & (lane_env ? 1u : 0u);
 
     // ---- Agent.move (environment.py:141-155), integer 0/1 flags
@@ -178,9 +180,18 @@ __device__ __forceinline__ uint4 group_phase_c(const WfArgs &a, const EnvRegs &S
 //   lanes busy instead of G of them), the registers travel through LDS, the 64/G waves each run
 //   phase B for G environments, and whichever wave finishes last runs phase C for all 64.  This
 //   divides the per-environment instruction cost of phases A and C by 64/G.
-template <int W, int H, bool SHARED, bool RARE>
+// WIND: wind with a direction (wf_params.wind_mode != 0; environment.py:187-193, 260-287).  The heat a burning cell hands
+// to a neighbour depends on the direction between them, so a grass cell keeps one count per direction (a.wind_cnt: a
+// dword per cell, bytes = addends received from the cell below / above / left / right, i.e. heating it N / S / E / W) and
+// ignites when the float64 sum of count x addend exceeds the threshold; the environment's four addends are
+// wave-uniform (scalar loads from the table the host computed with the reference's own expression), the four "neighbour
+// still burning" bits are the lane bits of the same masks the calm rule counts.  Plane 2 then only records how a cell was
+// ignited.  No count a cell can reach brings the sum within rounding distance of the threshold (wf_create checks it), so
+// the order in which the reference adds its addends decides nothing.
+template <int W, int H, bool SHARED, bool RARE, bool WIND = false>
 __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_step_group(const WfArgs a)
 {
+    static_assert(!(SHARED && WIND), "wind runs on the private variant");
     constexpr int CELLS = W * H, LANES = CELLS / 4;
     constexpr uint32_t ENV_BYTES = CELLS * 4;
     const uint32_t lane = __lane_id();
@@ -255,12 +266,16 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
     obs_offsets<W, H>(lane, oj);
     if (active) {
         uint4 raw_next = *reinterpret_cast<const uint4 *>(planes_b + (e0 * ENV_BYTES + lane_off));
+        uint4 cnt_next = make_uint4(0, 0, 0, 0);
+        if constexpr (WIND) cnt_next = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.wind_cnt) + (e0 * ENV_BYTES + lane_off));
         for (uint32_t k = 0; k < ng; ++k) {
             const uint32_t e = e0 + k;
             const uint4 raw = raw_next;
+            const uint4 cnt_raw = cnt_next;
             {   // prefetch the next environment of the group (clamped: the last one re-reads itself)
                 const uint32_t en = e0 + min(k + 1u, ng - 1u);
                 raw_next = *reinterpret_cast<const uint4 *>(planes_b + (en * ENV_BYTES + lane_off));
+                if constexpr (WIND) cnt_next = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.wind_cnt) + (en * ENV_BYTES + lane_off));
             }
             const uint32_t P = __builtin_amdgcn_readlane(Pv, k);
             uint32_t R = 0;
@@ -284,6 +299,8 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     for (int j = 0; j < 4; ++j)
                         r[j] = t[j] | (u[j] << 8) | (h[j] << 16) | ((lane == (qs >> 2) && (qs & 3u) == (uint32_t)j) ? (1u << 24) : 0u);
                     *reinterpret_cast<uint4 *>(planes_b + (e * ENV_BYTES + lane_off)) = make_uint4(r[0], r[1], r[2], r[3]);
+                    if constexpr (WIND)      // a fresh grid has received no heat
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.wind_cnt) + (e * ENV_BYTES + lane_off)) = make_uint4(0, 0, 0, 0);
                     if (a.obs) emit_obs<W, H>(obs_lds, a.obs + (size_t)e * (CELLS * 3), r, oj, lane);
                     if constexpr (SHARED) {
                         if (lane == 0) {
@@ -323,6 +340,19 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     c[j] = pk_add_u16(c[j], lanebit(F) ? d : 0u);
                 }
                 uint32_t ign_bits = 0;
+                // wind: this environment's addends per direction and its count words (one dword per cell)
+                double wc0 = 0.0, wc1 = 0.0, wc2 = 0.0, wc3 = 0.0, threshold = 0.0;
+                uint32_t n[4] = { 0, 0, 0, 0 }, nchg = 0;
+                char *cnt_p = nullptr;
+                if constexpr (WIND) {
+                    const uint32_t code = (uint32_t)__builtin_amdgcn_readlane(S.fl, k) >> 16;
+                    cold_ptr cc = (cold_ptr)(uintptr_t)a.cold;
+                    const double __attribute__((address_space(4))) *tab = cc->wind_c[(code >> 4) & 3u][code & 15u];
+                    wc0 = tab[0]; wc1 = tab[1]; wc2 = tab[2]; wc3 = tab[3];
+                    threshold = cc->p.threshold;
+                    cnt_p = reinterpret_cast<char *>(a.wind_cnt) + (e * ENV_BYTES + lane_off);
+                    n[0] = cnt_raw.x; n[1] = cnt_raw.y; n[2] = cnt_raw.z; n[3] = cnt_raw.w;
+                }
                 static_for<4>([&](auto J) {
                     constexpr int j = decltype(J)::value;
                     using C = CM<W, H, j>;
@@ -333,16 +363,39 @@ __global__ __launch_bounds__(SHARED ? 512 : 256, SHARED ? 8 : WF_LB) void wf_ste
                     u64 RT = j < 3 ? STILL[(j + 1) & 3] : (STILL[0] >> 1);
                     if (C::NOT_X0 != C::VALID) LF &= C::NOT_X0;
                     if (C::NOT_XL != C::VALID) RT &= C::NOT_XL;
-                    const uint32_t cnt = (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
-                                         (lanebit(LF) ? 1u : 0u) + (lanebit(RT) ? 1u : 0u);
-                    const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
-                    const u64 IGN = GR & __ballot(cnt >= room);
-                    const uint32_t ig = lanebit(IGN) ? 1u : 0u;
-                    const uint32_t cn = c[j] + (min(cnt, room) << 16) + ig;        // heat saturates; grass -> fire
-                    c[j] = lanebit(GR) ? cn : c[j];
-                    ign_bits |= ig << j;
+                    u64 IGN;
+                    if constexpr (WIND) {
+                        // direction k of the vector burning cell -> this cell: the cell BELOW heats it northwards (k = 0),
+                        // the one above southwards (1), the left one eastwards (2), the right one westwards (3)
+                        uint32_t inc = (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) | (lanebit(nb_up<W, H, j>(STILL)) ? 0x100u : 0u) |
+                                       (lanebit(LF) ? 0x10000u : 0u) | (lanebit(RT) ? 0x1000000u : 0u);
+                        inc = lanebit(GR) ? inc : 0u;
+                        // a count byte saturates at 255 (bytes that are 0xFF take no increment)
+                        const uint32_t full = ((((n[j] & 0x7f7f7f7fu) + 0x01010101u) & n[j]) & 0x80808080u) >> 7;
+                        const uint32_t nn = n[j] + (inc & ~full);
+                        const double temp = (double)(nn & 0xffu) * wc0 + (double)((nn >> 8) & 0xffu) * wc1 +
+                                            (double)((nn >> 16) & 0xffu) * wc2 + (double)(nn >> 24) * wc3;
+                        IGN = GR & __ballot(inc != 0u && temp > threshold);           // a new addend arrived and the sum is over
+                        nchg |= nn ^ n[j];
+                        n[j] = nn;
+                        const uint32_t ig = lanebit(IGN) ? 1u : 0u;
+                        c[j] = ig ? (c[j] | ((uint32_t)WF_HEAT_IGNITED << 16)) + 1u : c[j];     // grass -> fire, marked "ignited by heat"
+                        ign_bits |= ig << j;
+                    } else {
+                        const uint32_t cnt = (lanebit(nb_up<W, H, j>(STILL)) ? 1u : 0u) + (lanebit(nb_dn<W, H, j>(STILL)) ? 1u : 0u) +
+                                             (lanebit(LF) ? 1u : 0u) + (lanebit(RT) ? 1u : 0u);
+                        const uint32_t room = ign - ((c[j] >> 16) & 0xffu);            // quanta still missing (>= 1 on grass)
+                        IGN = GR & __ballot(cnt >= room);
+                        const uint32_t ig = lanebit(IGN) ? 1u : 0u;
+                        const uint32_t cn = c[j] + (min(cnt, room) << 16) + ig;        // heat saturates; grass -> fire
+                        c[j] = lanebit(GR) ? cn : c[j];
+                        ign_bits |= ig << j;
+                    }
                     FIRE[j] = STILL[j] | IGN;
                 });
+                if constexpr (WIND) {
+                    if (nchg) *reinterpret_cast<uint4 *>(cnt_p) = make_uint4(n[0], n[1], n[2], n[3]);
+                }
                 // set_fire_to :245-246: a newly ignited border cell
                 R |= __ballot((ign_bits & bgeo) != 0u) ? RB_BORDER : 0u;
             } else {
