@@ -355,8 +355,8 @@ def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
 
 
 def test_big_grid_split_equals_single_launch_and_oracle(wf, monkeypatch):
-    """Big-grid jobs (>= 8 Mi cells) on the context's own streams run as two shares of the batch on two
-    streams; the result must not depend on it (reset streams are keyed by the context-level env index)."""
+    """Big-grid jobs (>= 8 Mi cells) on the context's own streams run as shares of the batch on as many streams (three
+    by default); the result must not depend on it (reset streams are keyed by the context-level env index)."""
     W = H = 64
     B, T = 2100, 24
     kw = dict(width=W, height=H, seed=9, auto_reset=True, containment=True, fuel_range=(2, 5), ignite_ppm=30000)
@@ -1112,9 +1112,9 @@ def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
 
 def test_config4_1024x256x256_full_size(wf, monkeypatch):
     """BASELINE configs[3] at its stated size: 1 024 batched 256x256 grids, ~1 % of the cells pre-ignited, fuel
-    U{10..40}.  The job takes the two-stream split of the in-place tiled kernel (wf_tiled_prologue -> wf_step_tiled on two
-    shares of the batch); a WF_NO_SPLIT twin must agree bit for bit on every plane, a strided sample of 32
-    environments (both shares, the seam and the last env) is replayed by the oracle, and the monotonicity laws
+    U{10..40}.  The job takes the default split of the in-place tiled kernel (wf_tiled_prologue -> wf_step_tiled on three
+    shares of the batch, on three streams); a WF_NO_SPLIT twin must agree bit for bit on every plane, a strided sample of 32
+    environments (all shares, the seams and the last env) is replayed by the oracle, and the monotonicity laws
     of the rule are checked on ALL cells.  30 no-op ticks (the configuration), then 12 steps with agents digging."""
     B, S = 1024, 256
     kw = dict(size=S, seed=44, fuel_range=(10, 40), ignite_ppm=10000, containment=True)
