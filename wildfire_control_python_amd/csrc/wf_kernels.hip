@@ -324,6 +324,9 @@ __global__ __launch_bounds__(256) void wf_get_state_wave(const uint32_t *__restr
 //            bytes of the range go out as byte stores.
 // 7 B of traffic per cell (4 read + 3 written).  The kernel it replaces ran one thread per output triple with 64-bit
 // div / mod and read the planes at a stride of 4W bytes: 0.65 TB/s at 1 024 x 256x256.
+#ifndef WF_GS_BUDGET
+#define WF_GS_BUDGET 9216    // wf_get_state_cols: dwords of LDS a workgroup's tile may take (36 KiB: four workgroups per CU; 18 and 64 KiB measured slower)
+#endif
 __device__ __forceinline__ uint32_t obs_triple(uint32_t c)
 {
     const uint32_t t = c & 0xffu;
@@ -337,26 +340,32 @@ __global__ __launch_bounds__(256) void wf_get_state_cols(const uint32_t *__restr
     const uint32_t TXG = 1u << txg_log2, Hp = H | 1u, pad = Hp - H;
     const uint32_t X0 = blockIdx.x << txg_log2;
     const uint32_t nX = min(TXG, ncols - X0);
-    // ---- phase 1
+    // ---- phase 1 (U independent row loads in flight per thread: 8 for tall grids - 1 024 x 256x256 109 -> 99 us -, 4 for
+    // short ones, whose columns a thread finishes in one or two trips anyway)
     {
         const uint32_t lx = threadIdx.x & (TXG - 1u), ly = threadIdx.x >> txg_log2, ystep = 256u >> txg_log2;
         if (lx < nX) {
             const uint32_t X = X0 + lx, b = X / W, x = X - b * W;
             const uint32_t *src = planes + (size_t)b * H * W + x;
             uint32_t *dst = tile + lx * Hp;
-            for (uint32_t y = ly; y < H; y += ystep * 4u) {          // four independent loads in flight
-                uint32_t v[4];
+            auto rows = [&](auto UU) {
+                constexpr int U = decltype(UU)::value;
+                for (uint32_t y = ly; y < H; y += ystep * (uint32_t)U) {
+                    uint32_t v[U];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t yy = y + (uint32_t)k * ystep;
-                    v[k] = yy < H ? src[(size_t)yy * W] : 0u;
-                }
+                    for (int k = 0; k < U; ++k) {
+                        const uint32_t yy = y + (uint32_t)k * ystep;
+                        v[k] = yy < H ? src[(size_t)yy * W] : 0u;
+                    }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t yy = y + (uint32_t)k * ystep;
-                    if (yy < H) dst[yy] = obs_triple(v[k]);
+                    for (int k = 0; k < U; ++k) {
+                        const uint32_t yy = y + (uint32_t)k * ystep;
+                        if (yy < H) dst[yy] = obs_triple(v[k]);
+                    }
                 }
-            }
+            };
+            if (H >= 8u * ystep) rows(std::integral_constant<int, 8>{});
+            else rows(std::integral_constant<int, 4>{});
         }
     }
     __syncthreads();
@@ -725,7 +734,7 @@ hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, i
     const unsigned Hp = (unsigned)H | 1u;
     if (Hp <= 16000u && ncols < (1ull << 31) && (unsigned long long)H * 3ull * 64ull < (1ull << 31)) {
         unsigned lg = 0;
-        while (lg < 6u && (2u << lg) * Hp <= 9216u) ++lg;            // largest TXG = 2^lg <= 64 whose tile fits
+        while (lg < 6u && (2u << lg) * Hp <= (unsigned)WF_GS_BUDGET) ++lg;   // largest TXG = 2^lg <= 64 whose tile fits
         while (lg > 0u && (ncols >> lg) < 1024ull) --lg;             // small jobs: more, smaller workgroups
         const unsigned nblk = (unsigned)((ncols + (1ull << lg) - 1) >> lg);
         hipLaunchKernelGGL(wf_get_state_cols, dim3(nblk), dim3(256), (size_t)(1u << lg) * Hp * 4u, s, planes, obs,
