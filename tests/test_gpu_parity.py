@@ -1566,6 +1566,35 @@ def test_lent_host_buffers_spare_the_copies_and_change_nothing(wf, B):
     b_env.close()
 
 
+@pytest.mark.parametrize("S", [14, 13])
+def test_wind_count_bytes_saturate_at_255_like_the_oracle(wf, S):
+    """A count byte that has reached 255 takes no further addend (the oracle's `if (cnt < 255) cnt += 1`): uploaded counts
+    of 250..255 next to fires that never ignite anything (wind speed 0: a third of the winds "random" draws) - the wave
+    family's wind kernel (14x14) and the generic family (13x13), 40 steps."""
+    from tests.golden_util import WIND_SPEEDS
+    B = 96
+    env = wf.BatchedForestFire(B, size=S, seed=2, fuel_range=(30, 60), ignite_ppm=20000, metadata={"wind": "random"})
+    env.reset(seed=2)
+    op = O.default_params(fuel_lo=30, fuel_hi=60, ignite_ppm=20000, wind_mode=2, wind_speeds=WIND_SPEEDS + [0.0])
+    planes, envs = O.new_state(B, S, S)
+    counts = np.zeros(planes.shape, np.uint8)
+    O.reset(planes, envs, seed=2, params=op, counts=counts)
+    rng = np.random.default_rng(S)
+    envs["wind"] = O.wind_code(1, -1, 0)                       # speed index 0 = no heat at all: nothing ever ignites
+    counts[:] = rng.integers(250, 256, size=counts.shape).astype(np.uint8) * (planes[..., 0:1] == 0)
+    env.upload(planes, envs, counts)
+    for t in range(40):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        _, r, d, _ = env.step(a)
+        ro, do = O.step(planes, envs, a, op, counts=counts)
+        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(env.download_counts(), counts, err_msg=f"counts t={t}")
+    gp, _ = env.download()
+    np.testing.assert_array_equal(gp, planes)
+    assert (counts == 255).sum() > (counts == 254).sum() > 0 and not (planes[..., 2] == O.HEAT_IGNITED).any()
+    env.close()
+
+
 def test_upload_of_planes_resets_the_wind_counts(wf):
     """Planes and per-direction heat counts form one state (include/wildfire.h: wf_upload): uploading planes alone starts
     from zero heat, it never keeps the counts of the grid that was there before."""
