@@ -1831,7 +1831,8 @@ def test_sharded_forest_fire_equals_one_context(wf):
     reset streams are keyed by the global environment id."""
     import torch
     G, S = 10007, 14
-    kw = dict(seed=5, auto_reset=True, fuel_range=(6, 14), containment=True)
+    # (a_speed = 2: ONE counter drives every shard, whichever front end - host or device - issues the step)
+    kw = dict(seed=5, auto_reset=True, fuel_range=(6, 14), containment=True, metadata={"a_speed": 2})
     sh = wf.ShardedForestFire(G, size=S, devices=(0, 0, 0, 0), **kw)
     one = wf.BatchedForestFire(G, size=S, **kw)
     np.testing.assert_array_equal(sh.reset(seed=9), one.reset(seed=9))

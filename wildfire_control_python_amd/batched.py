@@ -327,7 +327,7 @@ class BatchedForestFire:
             self._staging = (n_steps, view(pa, ctypes.c_int8, np.int8), view(pr, ctypes.c_double, np.float64), view(pd, ctypes.c_uint8, np.uint8))
         return self._staging[1:]
 
-    def step_many(self, actions=None, n_steps=None, borrow=False):
+    def step_many(self, actions=None, n_steps=None, borrow=False, update_mask=None):
         """n_steps ForestFire.step() calls in one API call (small batches: ONE kernel launch, the grid stays in
         registers between ticks).  actions int8 (n_steps, batch) or None for no-ops.
         Returns (reward float64 (n_steps,batch), done bool (n_steps,batch)).
@@ -340,7 +340,7 @@ class BatchedForestFire:
             assert actions.shape[1] == self.batch
             n_steps = actions.shape[0]
         n_steps = int(n_steps or 1)
-        mask = self._update_mask(n_steps)
+        mask = self._update_mask(n_steps) if update_mask is None else int(update_mask)
         if self._staging is not None and n_steps > self._staging[0]:
             self._staging = None                      # a longer call re-allocates the lent buffers: the old views dangle
         if borrow:
@@ -353,9 +353,10 @@ class BatchedForestFire:
                                    N.ptr(reward), N.ptr(done)), "wf_step")
         return reward, done.astype(bool)
 
-    def step(self, actions=None):
+    def step(self, actions=None, update_mask=None):
         """[state (batch,W,H,3) int8, reward float64 (batch,), done bool (batch,), {}]
-        (forest_fire.py:30-49 with a batch axis)."""
+        (forest_fire.py:30-49 with a batch axis).  update_mask: bit 0 = run update() in this step (default: the a_speed
+        counter of METADATA decides, forest_fire.py:40-43)."""
         if actions is not None and not isinstance(actions, np.ndarray):
             actions = np.array([encode_action(a) for a in actions], dtype=np.int8)
         if actions is not None:
@@ -365,7 +366,8 @@ class BatchedForestFire:
         done = np.empty(self.batch, dtype=np.uint8)
         obs = np.empty((self.batch, self.width, self.height, 3), dtype=np.int8)
         # one launch: the observation is written by the step kernel itself
-        self._ck(self._lib.wf_step_obs(self._h, N.ptr(actions), 1, ctypes.c_uint64(self._update_mask(1)),
+        mask = self._update_mask(1) if update_mask is None else int(update_mask)
+        self._ck(self._lib.wf_step_obs(self._h, N.ptr(actions), 1, ctypes.c_uint64(mask),
                                        N.ptr(reward), N.ptr(done), N.ptr(obs)), "wf_step_obs")
         return [obs, reward, done.astype(bool), {}]
 

@@ -346,19 +346,38 @@ int ensure_staging(wf_ctx *c, int n_steps)
     return WF_OK;
 }
 
+// the pinned reward / done block for calls of n actions (and, only for the WF_HOST_STAGE_MIN experiment, device mirrors)
 int ensure_mirrors(wf_ctx *c, size_t n)
 {
-    if (n <= c->v_count) return WF_OK;
+    const bool want_dev = c->knobs.host_stage_min > 0;
+    if (n <= c->v_count && (!want_dev || c->v_out)) return WF_OK;
+    if (n < c->v_count) n = c->v_count;
     if (c->v_actions) (void)hipFree(c->v_actions);
     if (c->v_out) (void)hipFree(c->v_out);
-    if (c->p_out) (void)hipHostFree(c->p_out);
-    c->v_actions = nullptr; c->v_out = nullptr; c->p_out = nullptr; c->v_count = 0;
+    c->v_actions = nullptr; c->v_out = nullptr;
     const size_t na = (n + 15) & ~(size_t)15, no = (n * 9 + 15) & ~(size_t)15;
-    HIP_TRY(c, hipMalloc((void **)&c->v_actions, na));
-    HIP_TRY(c, hipMalloc((void **)&c->v_out, no));
-    HIP_TRY(c, hipHostMalloc((void **)&c->p_out, no, hipHostMallocDefault));
+    if (n > c->v_count || !c->p_out) {
+        if (c->p_out) (void)hipHostFree(c->p_out);
+        c->p_out = nullptr;
+        c->v_count = 0;
+        HIP_TRY(c, hipHostMalloc((void **)&c->p_out, no, hipHostMallocDefault));
+    }
+    if (want_dev) {
+        HIP_TRY(c, hipMalloc((void **)&c->v_actions, na));
+        HIP_TRY(c, hipMalloc((void **)&c->v_out, no));
+    }
     c->v_count = n;
     return WF_OK;
+}
+
+// WF_GRAPH experiment: captured launch sequences hold the launch arguments of the moment they were captured
+void drop_graphs(wf_ctx *c)
+{
+    for (wf_ctx::GraphEntry &g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
 }
 
 // One wf_step*_device call of the wave family: the launches, on the context's stream(s).
@@ -620,10 +639,7 @@ int wf_destroy(wf_ctx *c)
     for (hipStream_t sd : c->side)
         if (sd) (void)hipStreamSynchronize(sd);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (wf_ctx::GraphEntry &g : c->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
+    drop_graphs(c);
     void *pinned[] = { c->d_actions, c->h_obs, c->h_dl, c->p_out };
     for (void *b : pinned)
         if (b) (void)hipHostFree(b);
@@ -656,6 +672,7 @@ int wf_set_params(wf_ctx *c, const wf_params *p)
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drop_graphs(c);
     c->p = *p;
     // a changed containment switch makes cached reachability boards untrustworthy
     HIP_TRY(c, wf_launch_invalidate_reach(c->envs, c->batch, c->stream));
@@ -669,6 +686,7 @@ int wf_set_stream(wf_ctx *c, void *hip_stream)
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
     if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drop_graphs(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
@@ -1045,6 +1063,7 @@ int wf_reload_env(wf_ctx *c)
     JOIN(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int parts = c->n_parts;
+    drop_graphs(c);
     wf_read_knobs(&c->knobs);
     c->knobs.n_parts = parts;          // the side streams exist since wf_create: WF_SPLIT is fixed for a context's life
     // boards are kept per kernel layout: a switch of kernels must not meet a board the other layout left stale

@@ -117,13 +117,16 @@ class ShardedForestFire:
 
     def step(self, actions=None):
         import numpy as np
-        outs = [s.step(a) for s, a in zip(self.shards, self._split(actions))]
+        mask = self.shards[0]._update_mask(1)                     # ONE a_speed counter for the whole batch
+        outs = [s.step(a, update_mask=mask) for s, a in zip(self.shards, self._split(actions))]
         return [np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]),
                 np.concatenate([o[2] for o in outs]), {}]
 
     def step_many(self, actions=None, n_steps=None):
         import numpy as np
-        outs = [s.step_many(a, n_steps) for s, a in zip(self.shards, self._split(actions, axis=-1))]
+        n = int(n_steps or 1) if actions is None else (1 if np.ndim(actions) == 1 else np.shape(actions)[0])
+        mask = self.shards[0]._update_mask(n)
+        outs = [s.step_many(a, n_steps, update_mask=mask) for s, a in zip(self.shards, self._split(actions, axis=-1))]
         return np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1)
 
     def download(self):
