@@ -34,6 +34,7 @@ struct wf_ctx {
     hipEvent_t ev_side[WF_MAX_SIDE] = {}, ev_fork = nullptr;
     int n_parts = 2;                  // launches per step (WF_SPLIT overrides, 1 = never split)
     WfKnobs knobs = {};               // WF_* experiment switches, read once (wf_create / wf_reload_env)
+    bool sync_call = false;           // inside a synchronous host-buffer call: one launch, no fork / join (see wf_step_obs)
     bool side_pending = false;        // work enqueued on `side` that `stream` has not waited for yet
     bool main_touched = true;         // non-step work enqueued on `stream` since the last fork
     // device state
@@ -273,13 +274,13 @@ bool splits(const wf_ctx *c, int n_steps)
 {
     const int min_batch = c->knobs.split_min > 0 ? c->knobs.split_min : 4096 * c->n_parts;   // 8 192 envs: 7.9 vs 9.6 us per step; 4 096: 7.4 vs 6.8
     return c->fam == WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && n_steps == 1 && c->batch >= min_batch &&
-           !c->knobs.no_split;
+           !c->knobs.no_split && !c->sync_call;
 }
 
 bool splits_big(const wf_ctx *c)
 {
     return c->fam != WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && c->batch >= 2 * c->n_parts &&
-           (size_t)c->batch * c->H * c->W >= ((size_t)8 << 20) && !c->knobs.no_split;
+           (size_t)c->batch * c->H * c->W >= ((size_t)8 << 20) && !c->knobs.no_split && !c->sync_call;
 }
 
 // (re)publish the rarely needed parameters to the device
@@ -919,6 +920,13 @@ int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_m
     double *p_reward = reinterpret_cast<double *>(c->p_out);
     uint8_t *p_done = c->p_out + n * sizeof(double);
     if (actions && actions != c->d_actions) memcpy(c->d_actions, actions, n);
+    // A synchronous call gains nothing from the two-stream split of a large step - nothing else is in flight to overlap
+    // with - and pays its fork and join (events across streams): 88 -> 77 us per wf_step at 65 536 x 14x14, 67 -> 51 on lent
+    // buffers (tools/host_path_breakdown.py: a step + synchronisation with EVERY buffer in device memory is 57 us with the
+    // split, of which the step is 19: the kernels' own PCIe accesses add 5).  (Polling hipStreamQuery instead of
+    // hipStreamSynchronize was measured too: slower, 59 against 49 us per single-environment adapter step.)
+    // (single steps only: an n-step call of a large batch keeps its split and the rows kernel's step loop)
+    struct SyncCall { wf_ctx *c; SyncCall(wf_ctx *c_, bool on) : c(c_) { c->sync_call = on; } ~SyncCall() { c->sync_call = false; } } in_sync_call(c, n_steps == 1);
     // Experiment (WF_HOST_STAGE_MIN=n, off by default): calls of at least n actions go through DEVICE MIRRORS - bit 0 of
     // WF_HOST_STAGE_MODE: the actions come over with one coalesced copy kernel before the step; bit 1: reward / done
     // leave through a mirror and one copy kernel after it - instead of the step kernel reading and writing pinned host
