@@ -208,6 +208,13 @@ int wf_step_obs(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update
 int wf_step_obs_device(wf_ctx *ctx, const int8_t *d_actions, int n_steps, uint64_t update_mask,
                        double *d_reward, uint8_t *d_done, int8_t *d_obs);
 
+/* wf_step followed by wf_download of the resulting state under ONE stream synchronisation (planes / envs as in
+ * wf_download; either may be NULL).  What a host-side view of a small context wants after every step - the
+ * single-environment adapter, whose World.env / agents / burning_cells mirror the device state
+ * (forest_fire.py:46-49 returns get_state(), which the reference computes from World.env). */
+int wf_step_download(wf_ctx *ctx, const int8_t *actions, int n_steps, uint64_t update_mask,
+                     double *reward, uint8_t *done, int8_t *planes, wf_env *envs);
+
 /* World.get_state() (environment.py:399-402) for the whole batch. */
 int wf_get_state(wf_ctx *ctx, int8_t *obs);
 int wf_get_state_device(wf_ctx *ctx, int8_t *d_obs);

@@ -1538,6 +1538,28 @@ def test_get_state_kernel_any_shape_any_alignment(wf, W, H, B):
     env.close()
 
 
+@pytest.mark.parametrize("B,W,H", [(1, 14, 14), (7, 10, 10), (300, 13, 11), (5000, 14, 14), (40, 64, 64)])
+def test_step_download_equals_step_then_download(wf, B, W, H):
+    """wf_step_download: the step and the state it leaves under one synchronisation - small contexts through the
+    copy-kernel path, larger ones by DMA; same results as wf_step followed by wf_download."""
+    a_env = wf.BatchedForestFire(B, width=W, height=H, seed=4, auto_reset=True, fuel_range=(4, 12))
+    b_env = wf.BatchedForestFire(B, width=W, height=H, seed=4, auto_reset=True, fuel_range=(4, 12))
+    a_env.reset(seed=4)
+    b_env.reset(seed=4)
+    rng = np.random.default_rng(B)
+    for t in range(25):
+        a = rng.integers(0, 6, size=B).astype(np.int8)
+        r1, d1, p1, e1 = a_env.step_download(a)
+        r2, d2 = b_env.step_many(a)
+        p2, e2 = b_env.download()
+        np.testing.assert_array_equal(r1, r2[0])
+        np.testing.assert_array_equal(d1, d2[0])
+        np.testing.assert_array_equal(p1, p2, err_msg=f"planes t={t}")
+        np.testing.assert_array_equal(e1, e2, err_msg=f"envs t={t}")
+    a_env.close()
+    b_env.close()
+
+
 @pytest.mark.parametrize("B", [1, 300, 16384, 70000])
 def test_lent_host_buffers_spare_the_copies_and_change_nothing(wf, B):
     """wf_host_staging lends the pinned buffers wf_step works on; a call that is handed them back reads and writes them in

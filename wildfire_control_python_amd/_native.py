@@ -78,6 +78,7 @@ SYMBOLS = [
     ("wf_step", _i, [_vp, _vp, _i, _u64, _vp, _vp]),
     ("wf_step_device", _i, [_vp, _vp, _i, _u64, _vp, _vp]),
     ("wf_step_obs", _i, [_vp, _vp, _i, _u64, _vp, _vp, _vp]),
+    ("wf_step_download", _i, [_vp, _vp, _i, _u64, _vp, _vp, _vp, _vp]),
     ("wf_host_staging", _i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     ("wf_step_obs_device", _i, [_vp, _vp, _i, _u64, _vp, _vp, _vp]),
     ("wf_get_state", _i, [_vp, _vp]),

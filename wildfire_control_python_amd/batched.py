@@ -353,6 +353,21 @@ class BatchedForestFire:
                                    N.ptr(reward), N.ptr(done)), "wf_step")
         return reward, done.astype(bool)
 
+    def step_download(self, actions=None):
+        """One step and the resulting state under ONE synchronisation (wf_step_download):
+        (reward float64 (batch,), done bool (batch,), planes int8 (batch,H,W,4), envs ENV_DTYPE (batch,)).
+        For host-side views of small contexts (the single-environment adapter); large batches belong on the device API."""
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.int8)
+            assert actions.shape == (self.batch,)
+        reward = np.empty(self.batch, dtype=np.float64)
+        done = np.empty(self.batch, dtype=np.uint8)
+        planes = np.empty((self.batch, self.height, self.width, 4), dtype=np.int8)
+        envs = np.empty(self.batch, dtype=N.ENV_DTYPE)
+        self._ck(self._lib.wf_step_download(self._h, N.ptr(actions), 1, ctypes.c_uint64(self._update_mask(1)),
+                                            N.ptr(reward), N.ptr(done), N.ptr(planes), N.ptr(envs)), "wf_step_download")
+        return reward, done.astype(bool), planes, envs
+
     def step(self, actions=None, update_mask=None):
         """[state (batch,W,H,3) int8, reward float64 (batch,), done bool (batch,), {}]
         (forest_fire.py:30-49 with a batch axis).  update_mask: bit 0 = run update() in this step (default: the a_speed

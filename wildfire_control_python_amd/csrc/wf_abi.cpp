@@ -477,6 +477,45 @@ int wave_step_graph(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
     return WF_OK;
 }
 
+// wf_download in two halves, so that a host-buffer step can bring the state back under ITS synchronisation
+// (wf_step_download): enqueue the device -> host movement on the context's stream; after the stream has been
+// synchronised, hand the bytes to the caller.
+struct Download { int8_t *planes; wf_env *envs; size_t pb, eb; bool small; };
+
+int download_enqueue(wf_ctx *c, int8_t *planes, wf_env *envs, Download *d)
+{
+    const size_t cells = (size_t)c->batch * c->H * c->W;
+    d->planes = planes;
+    d->envs = envs;
+    d->pb = planes ? cells * 4 : 0;
+    d->eb = envs ? (size_t)c->batch * sizeof(wf_env) : 0;
+    d->small = d->pb + d->eb <= WF_ZC_OBS_MAX;
+    if (d->small) {
+        // small contexts (the single-environment adapter refreshes its view after every step): copy kernels into
+        // pinned host memory instead of a DMA operation per array
+        if (c->h_dl_bytes < d->pb + d->eb) {
+            if (c->h_dl) (void)hipHostFree(c->h_dl);
+            c->h_dl = nullptr;
+            c->h_dl_bytes = 0;
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_dl, d->pb + d->eb, hipHostMallocDefault));
+            c->h_dl_bytes = d->pb + d->eb;
+        }
+        if (d->pb) HIP_TRY(c, wf_launch_copy_words(c->planes, c->h_dl, d->pb, c->stream));
+        if (d->eb) HIP_TRY(c, wf_launch_copy_words(c->envs, c->h_dl + d->pb, d->eb, c->stream));
+        return WF_OK;
+    }
+    if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, d->pb, hipMemcpyDeviceToHost, c->stream));
+    if (envs) HIP_TRY(c, hipMemcpyAsync(envs, c->envs, d->eb, hipMemcpyDeviceToHost, c->stream));
+    return WF_OK;
+}
+
+void download_finish(wf_ctx *c, const Download &d)
+{
+    if (!d.small) return;
+    if (d.pb) memcpy(d.planes, c->h_dl, d.pb);
+    if (d.eb) memcpy(d.envs, c->h_dl + d.pb, d.eb);
+}
+
 }  // namespace
 
 extern "C" {
@@ -723,28 +762,11 @@ int wf_download(wf_ctx *c, int8_t *planes, wf_env *envs)
     if (!c) return WF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     JOIN(c);
-    const size_t cells = (size_t)c->batch * c->H * c->W;
-    const size_t pb = planes ? cells * 4 : 0, eb = envs ? (size_t)c->batch * sizeof(wf_env) : 0;
-    if (pb + eb <= WF_ZC_OBS_MAX) {
-        // small contexts (the single-environment adapter refreshes its view after every step): copy kernels into
-        // pinned host memory instead of a DMA operation per array
-        if (c->h_dl_bytes < pb + eb) {
-            if (c->h_dl) (void)hipHostFree(c->h_dl);
-            c->h_dl = nullptr;
-            c->h_dl_bytes = 0;
-            HIP_TRY(c, hipHostMalloc((void **)&c->h_dl, pb + eb, hipHostMallocDefault));
-            c->h_dl_bytes = pb + eb;
-        }
-        if (pb) HIP_TRY(c, wf_launch_copy_words(c->planes, c->h_dl, pb, c->stream));
-        if (eb) HIP_TRY(c, wf_launch_copy_words(c->envs, c->h_dl + pb, eb, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (pb) memcpy(planes, c->h_dl, pb);
-        if (eb) memcpy(envs, c->h_dl + pb, eb);
-        return WF_OK;
-    }
-    if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, cells * 4, hipMemcpyDeviceToHost, c->stream));
-    if (envs) HIP_TRY(c, hipMemcpyAsync(envs, c->envs, (size_t)c->batch * sizeof(wf_env), hipMemcpyDeviceToHost, c->stream));
+    Download d;
+    int rc = download_enqueue(c, planes, envs, &d);
+    if (rc != WF_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    download_finish(c, d);
     return WF_OK;
 }
 
@@ -901,8 +923,23 @@ int wf_host_staging(wf_ctx *c, int n_steps, int8_t **actions, double **reward, u
     return WF_OK;
 }
 
+static int host_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask, double *reward, uint8_t *done, int8_t *obs,
+                     int8_t *planes, wf_env *envs);
+
 int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
                 double *reward, uint8_t *done, int8_t *obs)
+{
+    return host_step(c, actions, n_steps, update_mask, reward, done, obs, nullptr, nullptr);
+}
+
+int wf_step_download(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
+                     double *reward, uint8_t *done, int8_t *planes, wf_env *envs)
+{
+    return host_step(c, actions, n_steps, update_mask, reward, done, nullptr, planes, envs);
+}
+
+static int host_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask, double *reward, uint8_t *done, int8_t *obs,
+                     int8_t *planes, wf_env *envs)
 {
     if (!c || n_steps < 1 || n_steps > 64) return WF_ERR_ARG;
     int rc = ensure_host_staging(c, n_steps);
@@ -955,10 +992,16 @@ int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_m
         JOIN(c);
     }
     if (obs && !zc_obs) HIP_TRY(c, hipMemcpyAsync(obs, c->d_obs, nobs, hipMemcpyDeviceToHost, c->stream));
+    Download dl = { nullptr, nullptr, 0, 0, false };
+    if (planes || envs) {           // the resulting state comes back under the same synchronisation (wf_step_download)
+        rc = download_enqueue(c, planes, envs, &dl);
+        if (rc != WF_OK) return rc;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (zc_obs) memcpy(obs, c->h_obs, nobs);
     if (reward && reward != p_reward) memcpy(reward, p_reward, n * sizeof(double));
     if (done && done != p_done) memcpy(done, p_done, n);
+    download_finish(c, dl);
     return WF_OK;
 }
 

@@ -74,8 +74,8 @@ class World:
         self._burning_cells, self._border_points, self._contained = None, None, False
 
     # -- refreshed after every reset/step
-    def _refresh(self):
-        planes, envs = self._sim._b.download()
+    def _refresh(self, state=None):
+        planes, envs = state if state is not None else self._sim._b.download()
         self._planes, self._env = planes[0], envs[0]
         b = self._sim._b
         if b.wind_mode != N.WIND_CALM:                           # environment.py:187-193
@@ -254,12 +254,12 @@ class ForestFire:
             # the reference indexes W.agents[0] here and raises IndexError (forest_fire.py:33)
             raise IndexError("list index out of range")
         a = np.array([encode_action(action)], dtype=np.int8)
-        reward, _ = self._b.step_many(a, 1)
-        r = float(reward[0, 0])
+        reward, _, planes, envs = self._b.step_download(a)       # the step and the state it leaves, one synchronisation
+        r = float(reward[0])
         self.W._last_reward = int(r) if r == int(r) and r in (
             self.METADATA["default_reward"], self.METADATA["death_penalty"],
             self.METADATA["contained_bonus"]) else r
-        self.W._refresh()
+        self.W._refresh((planes, envs))
         return [self.W.get_state(), self.W._last_reward, not self.W.RUNNING, {}]
 
     def reset(self):                                            # forest_fire.py:52-54
