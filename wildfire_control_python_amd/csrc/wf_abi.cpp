@@ -500,8 +500,9 @@ int download_enqueue(wf_ctx *c, int8_t *planes, wf_env *envs, Download *d)
             HIP_TRY(c, hipHostMalloc((void **)&c->h_dl, d->pb + d->eb, hipHostMallocDefault));
             c->h_dl_bytes = d->pb + d->eb;
         }
-        if (d->pb) HIP_TRY(c, wf_launch_copy_words(c->planes, c->h_dl, d->pb, c->stream));
-        if (d->eb) HIP_TRY(c, wf_launch_copy_words(c->envs, c->h_dl + d->pb, d->eb, c->stream));
+        if (d->pb && d->eb) HIP_TRY(c, wf_launch_copy_words2(c->planes, c->h_dl, d->pb, c->envs, c->h_dl + d->pb, d->eb, c->stream));
+        else if (d->pb) HIP_TRY(c, wf_launch_copy_words(c->planes, c->h_dl, d->pb, c->stream));
+        else if (d->eb) HIP_TRY(c, wf_launch_copy_words(c->envs, c->h_dl + d->pb, d->eb, c->stream));
         return WF_OK;
     }
     if (planes) HIP_TRY(c, hipMemcpyAsync(planes, c->planes, d->pb, hipMemcpyDeviceToHost, c->stream));

@@ -131,5 +131,6 @@ bool wf_tiled_fused_obs(int H, int W);   // wf_step_tiled writes World.get_state
 hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s);
 hipError_t wf_launch_invalidate_reach(wf_env *envs, int batch, hipStream_t s);
 hipError_t wf_launch_copy_words(const void *src, void *dst, size_t bytes, hipStream_t s);   // bytes: a multiple of 4
+hipError_t wf_launch_copy_words2(const void *src0, void *dst0, size_t bytes0, const void *src1, void *dst1, size_t bytes1, hipStream_t s);
 hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, int H, int W,
                                hipStream_t s);

@@ -436,6 +436,16 @@ __global__ __launch_bounds__(256) void wf_copy_words_kernel(const uint32_t *src,
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
 }
 
+// two ranges in one launch (planes + records of wf_download's small path: a launch costs more than the bytes)
+__global__ __launch_bounds__(256) void wf_copy_words2_kernel(const uint32_t *src0, uint32_t *dst0, uint32_t n0,
+                                                            const uint32_t *src1, uint32_t *dst1, uint32_t n1)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n0 + n1; i += gridDim.x * 256u) {
+        if (i < n0) dst0[i] = src0[i];
+        else dst1[i - n0] = src1[i - n0];
+    }
+}
+
 __global__ __launch_bounds__(256) void wf_copy_quads_kernel(const uint4 *src, uint4 *dst, uint32_t n)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
@@ -709,6 +719,16 @@ hipError_t wf_launch_copy_words(const void *src, void *dst, size_t bytes, hipStr
     unsigned blocks = (n + 255u) / 256u;
     if (blocks > 1024u) blocks = 1024u;
     if (n) hipLaunchKernelGGL(wf_copy_words_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t *>(src), static_cast<uint32_t *>(dst), n);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_copy_words2(const void *src0, void *dst0, size_t bytes0, const void *src1, void *dst1, size_t bytes1, hipStream_t s)
+{
+    const uint32_t n0 = (uint32_t)(bytes0 / 4), n1 = (uint32_t)(bytes1 / 4);
+    unsigned blocks = (n0 + n1 + 255u) / 256u;
+    if (blocks > 1024u) blocks = 1024u;
+    if (n0 + n1) hipLaunchKernelGGL(wf_copy_words2_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t *>(src0), static_cast<uint32_t *>(dst0), n0,
+                                    static_cast<const uint32_t *>(src1), static_cast<uint32_t *>(dst1), n1);
     return hipGetLastError();
 }
 
