@@ -25,6 +25,8 @@ from .utility import get_name, grass, layer, temp_from_count, type2ascii, type2g
 # look-up tables indexed by the boundary's type code (5 = burning dirt, 6 = blocked burnt, 13 = blocked fire:
 # include/wildfire.h; 7..12 are not used)
 _REF_TYPE = np.array([0, 1, 2, 3, 4, 3, 2, 0, 0, 0, 0, 0, 0, 1], dtype=np.int64)    # the type the reference's World.env would hold
+# World.get_state() per type code: (agent_pos filled in later, type == fire, fire_mobility != inf)
+_STATE_LUT = np.array([[0.0, float(c in (N.FIRE, N.FIRE_BLOCKED)), float(c < N.DIRT)] for c in range(14)])
 _ASCII = np.array([type2ascii[int(t)] for t in _REF_TYPE])
 _GRAY = np.array([type2gray[int(t)] for t in _REF_TYPE])
 
@@ -178,8 +180,9 @@ class World:
 
     def get_state(self):                                        # environment.py:399-402
         p = self._planes
-        t = p[:, :, N.P_TYPE].T
-        return np.dstack((p[:, :, N.P_AGENT].T.astype(np.float64), (t == N.FIRE) | (t == N.FIRE_BLOCKED), t < N.DIRT))
+        out = _STATE_LUT[p[:, :, N.P_TYPE].T]                    # float64 (W, H, 3), one table look-up per cell
+        out[:, :, 0] = p[:, :, N.P_AGENT].T
+        return out
 
     def get_reward(self):
         """Reward of the last step (the reference recomputes it with side effects on
