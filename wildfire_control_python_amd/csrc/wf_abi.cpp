@@ -6,6 +6,7 @@
 // usable HIP device wf_create fails with WF_ERR_NO_DEVICE.
 #include <math.h>
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <thread>
 #include <vector>
@@ -62,6 +63,8 @@ struct wf_ctx {
     int8_t *v_actions = nullptr;
     uint8_t *v_out = nullptr;          // [n doubles of reward][n bytes of done]
     uint8_t *p_out = nullptr;          // pinned host block of the same layout
+    uint32_t *p_flag = nullptr;        // pinned completion word of synchronous calls (WF_FLAG_WAIT)
+    uint32_t flag_seq = 0;
     size_t v_count = 0;                // n the mirrors were sized for
     void *dbg_timing = nullptr;       // measurement builds (WF_WAVE_TIMING) only
     WfSpawn spawn;
@@ -681,7 +684,7 @@ int wf_destroy(wf_ctx *c)
         if (sd) (void)hipStreamSynchronize(sd);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graphs(c);
-    void *pinned[] = { c->d_actions, c->h_obs, c->h_dl, c->p_out };
+    void *pinned[] = { c->d_actions, c->h_obs, c->h_dl, c->p_out, c->p_flag };
     for (void *b : pinned)
         if (b) (void)hipHostFree(b);
     void *bufs[] = { c->planes, c->planes_alt, c->envs, c->reach, c->d_mask, c->d_obs, c->d_cold, c->d_mode, c->d_acc, c->d_halo, c->wind_cnt,
@@ -927,6 +930,31 @@ int wf_host_staging(wf_ctx *c, int n_steps, int8_t **actions, double **reward, u
 static int host_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask, double *reward, uint8_t *done, int8_t *obs,
                      int8_t *planes, wf_env *envs);
 
+// End of a synchronous host-buffer call.  WF_FLAG_WAIT=us: a one-lane kernel behind everything the call enqueued writes
+// the call's sequence number to a pinned word and the host spins on it for at most that long before it falls back to
+// hipStreamSynchronize (which is also what reports a failed kernel).
+static hipError_t wait_stream(wf_ctx *c)
+{
+    if (c->knobs.flag_wait > 0) {
+        if (!c->p_flag) {
+            hipError_t e = hipHostMalloc((void **)&c->p_flag, 64, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            *c->p_flag = 0;
+        }
+        const uint32_t seq = ++c->flag_seq;
+        hipError_t e = wf_launch_flag(c->p_flag, seq, c->stream);
+        if (e != hipSuccess) return e;
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds(c->knobs.flag_wait);
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(c->p_flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+            __builtin_ia32_pause();
+            if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > budget) break;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
 int wf_step_obs(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t update_mask,
                 double *reward, uint8_t *done, int8_t *obs)
 {
@@ -998,7 +1026,7 @@ static int host_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t upd
         rc = download_enqueue(c, planes, envs, &dl);
         if (rc != WF_OK) return rc;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c));
     if (zc_obs) memcpy(obs, c->h_obs, nobs);
     if (reward && reward != p_reward) memcpy(reward, p_reward, n * sizeof(double));
     if (done && done != p_done) memcpy(done, p_done, n);
@@ -1082,7 +1110,7 @@ const char *wf_call_kernel_name(const wf_ctx *c, int n_steps)
     if (n_steps == 1 || c->fam != WF_FAM_WAVE || c->p.wind_mode != WF_WIND_CALM) return wf_step_kernel_name(c);
     const bool sp = splits(c, 1);
     const bool in_kernel = sp ? multi_rows_call(c, n_steps) : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps));
-    if (!in_kernel) return sp ? wf_step_kernel_name(c) : "wf_step_wave (fused ticks, one environment per wave)";
+    if (!in_kernel) return sp ? wf_step_kernel_name(c) : (c->knobs.fused_legacy ? "wf_step_wave (fused ticks, one environment per wave)" : "wf_step_ticks (fused ticks, one environment per wave, packed cells)");
     WfArgs a = base_args(c);
     a.n_steps = n_steps;
     if (sp) {

@@ -75,6 +75,8 @@ struct WfKnobs {
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
     int host_stage_mode; // WF_HOST_STAGE_MODE: 1 actions through a device mirror, 2 reward / done, 3 both (default of the experiment)
+    int fused_legacy;    // WF_FUSED_LEGACY: n-step calls of one environment per wave on wf_step_wave (unpacked cells, agent logic on the vector unit) instead of wf_step_ticks
+    int flag_wait;       // WF_FLAG_WAIT: synchronous host-buffer calls wait on a flag a one-lane kernel writes to pinned memory (us of spinning; 0 = hipStreamSynchronize)
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
@@ -131,6 +133,7 @@ bool wf_tiled_fused_obs(int H, int W);   // wf_step_tiled writes World.get_state
 hipError_t wf_launch_reset_big(const WfArgs &a, const uint8_t *sel, int sel_value, u64 seed, hipStream_t s);
 hipError_t wf_launch_invalidate_reach(wf_env *envs, int batch, hipStream_t s);
 hipError_t wf_launch_copy_words(const void *src, void *dst, size_t bytes, hipStream_t s);   // bytes: a multiple of 4
+hipError_t wf_launch_flag(uint32_t *flag, uint32_t value, hipStream_t s);
 hipError_t wf_launch_copy_words2(const void *src0, void *dst0, size_t bytes0, const void *src1, void *dst1, size_t bytes1, hipStream_t s);
 hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, int H, int W,
                                hipStream_t s);

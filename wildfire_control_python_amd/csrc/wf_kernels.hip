@@ -254,7 +254,8 @@ __device__ __forceinline__ void emit_obs(uint8_t *lds, int8_t *obs_e, const uint
     }
 }
 
-#include "wf_wave_fused.h"   // wf_step_wave: n fused steps, one environment per wave
+#include "wf_wave_fused.h"   // wf_step_wave: n fused steps, one environment per wave (round-1 formulation, WF_FUSED_LEGACY=1)
+#include "wf_wave_ticks.h"   // wf_step_ticks: n fused steps, one environment per wave, packed cells + scalar agent
 #include "wf_wave_group.h"   // wf_step_group + phases A / C
 #include "wf_wave_rows.h"    // wf_step_rows
 
@@ -520,8 +521,13 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.n_steps > 1 && !k.multi_rows) {
         if (a.hot_flags & WF_HOT_WIND) return hipErrorInvalidValue;     // (wind: the host issues n single-step launches)
-        if (rare) hipLaunchKernelGGL((wf_step_wave<W, H, true, true>), dim3(blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((wf_step_wave<W, H, true, false>), dim3(blocks), dim3(256), 0, s, a);
+        if (k.fused_legacy) {
+            if (rare) hipLaunchKernelGGL((wf_step_wave<W, H, true, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((wf_step_wave<W, H, true, false>), dim3(blocks), dim3(256), 0, s, a);
+        } else {
+            if (rare) hipLaunchKernelGGL((wf_step_ticks<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((wf_step_ticks<W, H, false>), dim3(blocks), dim3(256), 0, s, a);
+        }
     } else {
         const StepPlan p = plan_single<W, H>(a, k, num_cus);
         if (a.n_steps > 1 && p.kind != STEP_ROWS) return hipErrorInvalidValue;   // only the rows kernel has the step loop
@@ -559,7 +565,9 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
     return hipGetLastError();
 }
 
+#ifndef WF_WAVE_SHAPES   // (a kernel experiment may build one shape only: -D'WF_WAVE_SHAPES(X)=X(10,10)')
 #define WF_WAVE_SHAPES(X) X(8, 8) X(10, 10) X(12, 12) X(14, 14) X(16, 16) X(16, 8) X(8, 16) X(20, 10) X(10, 20)
+#endif
 
 hipError_t dispatch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus)
 {
@@ -604,6 +612,8 @@ void wf_read_knobs(WfKnobs *k)
     k->no_resident = !set("WF_RESIDENT");     // opt-in experiment (measured: no gain, profiles/r03_c2_variants.txt)
     k->graph = set("WF_GRAPH");
     k->host_stage_min = num("WF_HOST_STAGE_MIN", 0);
+    k->flag_wait = num("WF_FLAG_WAIT", 0);
+    k->fused_legacy = set("WF_FUSED_LEGACY");
     k->host_stage_mode = num("WF_HOST_STAGE_MODE", 0);
     k->multi_rows = 0;
 }
@@ -729,6 +739,19 @@ hipError_t wf_launch_copy_words2(const void *src0, void *dst0, size_t bytes0, co
     if (blocks > 1024u) blocks = 1024u;
     if (n0 + n1) hipLaunchKernelGGL(wf_copy_words2_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t *>(src0), static_cast<uint32_t *>(dst0), n0,
                                     static_cast<const uint32_t *>(src1), static_cast<uint32_t *>(dst1), n1);
+    return hipGetLastError();
+}
+
+// Completion flag of a synchronous host-buffer call: stream order puts it behind the step (and its copy kernels), the
+// host spins on the pinned word instead of sleeping on the queue's completion signal.
+__global__ void wf_flag_kernel(uint32_t *flag, uint32_t value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t wf_launch_flag(uint32_t *flag, uint32_t value, hipStream_t s)
+{
+    hipLaunchKernelGGL(wf_flag_kernel, dim3(1), dim3(1), 0, s, flag, value);
     return hipGetLastError();
 }
 
