@@ -235,8 +235,9 @@ int wf_timer_stop(wf_ctx *ctx, float *elapsed_ms);   /* synchronises */
 const char *wf_kernel_name(const wf_ctx *ctx);
 const char *wf_step_kernel_name(const wf_ctx *ctx);
 int wf_step_launches(const wf_ctx *ctx);
-int wf_call_launches(const wf_ctx *ctx, int n_steps);   /* kernel launches behind one wf_step*(n_steps) call */
-const char *wf_call_kernel_name(const wf_ctx *ctx, int n_steps);   /* the kernel behind a wf_step*(n_steps) call */
+int wf_call_launches(const wf_ctx *ctx, int n_steps);   /* kernel launches behind one wf_step*(n_steps) call WITH actions */
+const char *wf_call_kernel_name(const wf_ctx *ctx, int n_steps);   /* the kernel behind that call (an n-step call without
+                                                         * actions of a large batch may run on wf_step_ticks where this one does not) */
 
 /* Experiments and tests only: the WF_* environment switches (kernel variant, split on/off ...) are read once in
  * wf_create; this re-reads them for an existing context (synchronises; WF_SPLIT itself stays as created). */

@@ -1968,6 +1968,122 @@ def test_arbitrary_uploaded_states_match_oracle(wf, W, H, toggle):
     env.close()
 
 
+# ------------------------------------------------ the n-step kernel of one environment per wave (wf_step_ticks)
+@pytest.mark.parametrize("W,H", [(8, 8), (10, 10), (12, 12), (14, 14), (16, 16), (16, 8), (8, 16), (20, 10), (10, 20)])
+@pytest.mark.parametrize("md", [None, {"make_rivers": True, "allow_dig_toggle": True, "n_actions": 5}], ids=["default", "rivers+toggle"])
+def test_n_step_kernel_every_shape_and_variant(wf, monkeypatch, W, H, md):
+    """wf_step_ticks (packed cells, agent / flags / reward on the scalar unit) in its four loop variants - with and
+    without actions, every step updating or not (a_speed-style masks) - on every wave-family shape: calls of 2..64
+    steps (blocks of 16 steps: actions loaded, rewards / done flags stored per block; an auto-reset that falls on a
+    block's first or last step), auto-reset and frozen environments, containment floods and payments, rivers and the
+    dig toggle, step by step against the oracle; the round-1 kernel (WF_FUSED_LEGACY=1) leaves the same state."""
+    for k in ("WF_FUSED_LEGACY", "WF_MULTI_SMALL", "WF_NO_MULTI", "WF_GROUP"):
+        monkeypatch.delenv(k, raising=False)
+    B = 200
+    rare = md is not None
+    paid_total = 0
+    for auto in (True, False):
+        kw = dict(width=W, height=H, seed=31, auto_reset=auto, containment=True, fuel_range=(2, 7), metadata=md)
+        env = wf.BatchedForestFire(B, **kw)
+        assert env._lib.wf_call_kernel_name(env._h, 5).decode().startswith("wf_step_ticks"), env._lib.wf_call_kernel_name(env._h, 5)
+        monkeypatch.setenv("WF_FUSED_LEGACY", "1")
+        old = wf.BatchedForestFire(B, **kw)
+        monkeypatch.delenv("WF_FUSED_LEGACY")
+        assert old._lib.wf_call_kernel_name(old._h, 5).decode().startswith("wf_step_wave")
+        env.reset(seed=31)
+        old.reset(seed=31)
+        op = O.default_params(containment=1, fuel_lo=2, fuel_hi=7, allow_dig_toggle=int(rare), make_rivers=int(rare))
+        planes, envs = O.new_state(B, H, W)
+        O.reset(planes, envs, seed=31, params=op)
+        rng = np.random.default_rng(W * 11 + H + int(rare))
+        paid = resets = frozen = 0
+        for call, n in enumerate((2, 16, 17, 5, 33, 64, 15, 1, 32, 48)):
+            noop = call % 4 == 3                            # every fourth call carries no actions
+            mask = (1 << n) - 1 if call % 3 != 1 else int(rng.integers(1, 1 << min(n, 62))) | 1
+            acts = None if noop else np.empty((n, B), dtype=np.int8)
+            outs = []
+            for k in range(n):
+                a = None
+                if not noop:
+                    a = rng.integers(0, 6, size=B).astype(np.int8)
+                    a[:B // 2] = _circle_actions(envs[:B // 2], W, H, rng)
+                    acts[k] = a
+                stopped = (envs["flags"] & O.F_RUNNING) == 0
+                ro, do = O.step(planes, envs, a, op, do_update=bool((mask >> k) & 1))
+                if stopped.any() and auto:
+                    O.reset(planes, envs, seed=31, mask=stopped, params=op)
+                    ro[stopped], do[stopped] = 0.0, 0
+                    resets += int(stopped.sum())
+                frozen += int(stopped.sum()) if not auto else 0
+                outs.append((ro, do))
+                paid += int((ro == 1000.0).sum())
+            r, d = env.step_many(acts, n, update_mask=mask) if noop else env.step_many(acts, update_mask=mask)
+            r0, d0 = old.step_many(acts, n, update_mask=mask) if noop else old.step_many(acts, update_mask=mask)
+            for k in range(n):
+                np.testing.assert_array_equal(r[k], outs[k][0], err_msg=f"auto={auto} call {call} (n={n}) step {k}: reward")
+                np.testing.assert_array_equal(d[k], outs[k][1].astype(bool), err_msg=f"auto={auto} call {call} (n={n}) step {k}: done")
+            np.testing.assert_array_equal(r0, r)
+            np.testing.assert_array_equal(d0, d)
+            gp, ge = env.download()
+            np.testing.assert_array_equal(gp, planes, err_msg=f"auto={auto} call {call}: planes")
+            np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"auto={auto} call {call}: envs")
+            gp0, ge0 = old.download()
+            np.testing.assert_array_equal(gp0, gp)
+            np.testing.assert_array_equal(_envs(ge0), _envs(ge))
+        np.testing.assert_array_equal(env.get_state(), O.get_state(planes))
+        assert resets > B if auto else frozen > B, (auto, paid, resets, frozen)
+        paid_total += paid
+        env.close()
+        old.close()
+    if W * H <= 144:                                         # (the circling agents close their rings in time on the small grids)
+        assert paid_total > 0
+
+
+@pytest.mark.parametrize("W,H,B,noop", [(16, 16, 8192 + 17, False), (20, 10, 16384, False), (14, 14, 8192 + 5, True), (10, 10, 16384, True)])
+def test_n_step_calls_of_split_contexts_on_the_one_wave_kernel(wf, monkeypatch, W, H, B, noop):
+    """Batches that are stepped as two part launches per single step: an n-step call goes to ONE wf_step_ticks launch where
+    that was measured faster - shapes without a rows-layout step loop, and calls without actions - with results equal
+    to the oracle's, and single steps in between (the part launches) continue from the state it leaves."""
+    for k in ("WF_FUSED_LEGACY", "WF_MULTI_SMALL", "WF_NO_MULTI", "WF_GROUP", "WF_NO_SPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=41, auto_reset=True, containment=True, fuel_range=(2, 6))
+    assert env.step_launches == 2
+    rows = env.step_kernel.startswith("wf_step_rows")
+    assert env._lib.wf_call_launches(env._h, 8) == (2 if rows else 1)      # (the introspection speaks of calls with actions)
+    assert rows == noop
+    env.reset(seed=41)
+    op = O.default_params(containment=1, fuel_lo=2, fuel_hi=6)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=41, params=op)
+    rng = np.random.default_rng(W + H)
+    resets = 0
+    for call, n in enumerate((8, 1, 20, 1, 1, 16)):
+        acts = None if noop and n > 1 else np.empty((n, B), dtype=np.int8)
+        outs = []
+        for k in range(n):
+            a = None
+            if acts is not None:
+                a = rng.integers(0, 6, size=B).astype(np.int8)
+                a[:B // 2] = _circle_actions(envs[:B // 2], W, H, rng)
+                acts[k] = a
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, a, op)
+            if stopped.any():
+                O.reset(planes, envs, seed=41, mask=stopped, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+                resets += int(stopped.sum())
+            outs.append((ro, do))
+        r, d = env.step_many(acts, n)
+        for k in range(n):
+            np.testing.assert_array_equal(r[k], outs[k][0], err_msg=f"call {call} (n={n}) step {k}: reward")
+            np.testing.assert_array_equal(d[k], outs[k][1].astype(bool), err_msg=f"call {call} (n={n}) step {k}: done")
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"call {call}: planes")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"call {call}: envs")
+    assert resets > B // 2
+    env.close()
+
+
 # ------------------------------------------------ rows layout with an odd number of environments per iteration
 @pytest.mark.parametrize("W,H,group,B", [(8, 8, "7", 4096 + 37), (8, 8, "14", 4096 + 37), (16, 8, "6", 4096 + 37), (8, 16, "3", 4096 + 37),
                                          (8, 8, None, 40000), (8, 16, None, 36000), (16, 8, "12", 9000 + 11)])

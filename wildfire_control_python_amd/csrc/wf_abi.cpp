@@ -337,6 +337,19 @@ bool multi_rows_whole(const wf_ctx *c, int n_steps)
     return wf_multi_step_in_rows(c->fam, probe, c->knobs, c->num_cus);
 }
 
+// An n-step call of a SPLIT context as ONE launch of wf_step_ticks (one environment per wave, grid in registers across
+// the steps) instead of the rows kernel's step loop (rows_loop) or n single-step launches per part?  Measured at 16 steps
+// per call (tools/nstep_kernels.py, profiles/r03_nstep_kernels.txt; us per call, ticks against the alternative): without
+// actions 8 192 envs 29-31 against 53-113, 16 384 envs 54-57 against 69-129, 65 536 envs 200-211 against 129-226 where a
+// step loop exists and 206 against 336 where none does (16x16); with actions (the agent's gather and its scalar chain double
+// the step) 8 192 envs 61-63 against 56-68, 16 384 envs 116-119 against 76-95 - but 62 / 117 against 108 / 130 at 16x16.
+bool ticks_serves_split(const wf_ctx *c, bool has_actions, bool rows_loop)
+{
+    if (c->knobs.no_multi || c->knobs.multi_small) return false;      // (experiment switches ask for the other kernels)
+    if (!has_actions) return !rows_loop || c->batch <= 16384;
+    return !rows_loop && c->batch <= 16384;
+}
+
 int ensure_staging(wf_ctx *c, int n_steps)
 {
     if (n_steps <= c->staged_steps) return WF_OK;
@@ -393,12 +406,15 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
     // The verdict is reached ONCE, from the shape of the whole call, and handed to every part launch
     // (WfKnobs::multi_rows): a ragged last part must not fall back to another kernel on its own.
     const bool sp = splits(c, 1);
-    const bool in_kernel = n_steps > 1 && (sp ? multi_rows_call(c, n_steps)
+    const bool calm = c->p.wind_mode == WF_WIND_CALM;
+    const bool rows_loop = n_steps > 1 && sp && multi_rows_call(c, n_steps);
+    const bool ticks = n_steps > 1 && sp && calm && ticks_serves_split(c, d_actions != nullptr, rows_loop);   // one launch, not split
+    const bool in_kernel = n_steps > 1 && !ticks && (sp ? rows_loop
                                               : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps)));
     WfKnobs kn = c->knobs;
     kn.multi_rows = in_kernel ? 1 : 0;
     // (wind with a direction has a single-step kernel only: n single-step launches whatever the batch)
-    const bool each = n_steps > 1 && ((splits(c, 1) && !in_kernel) || c->p.wind_mode != WF_WIND_CALM);
+    const bool each = n_steps > 1 && ((sp && !in_kernel && !ticks) || !calm);
     const int n_launch = each ? n_steps : 1;
     const size_t cells = (size_t)c->H * c->W;
     for (int st = 0; st < n_launch; ++st) {
@@ -410,7 +426,7 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
         a.done = d_done ? d_done + soff : nullptr;
         a.n_steps = each ? 1 : n_steps;
         a.update_mask = each ? (update_mask >> st) & 1ull : update_mask;
-        const bool split = splits(c, in_kernel ? 1 : a.n_steps);
+        const bool split = !ticks && splits(c, in_kernel ? 1 : a.n_steps);
         if (!split) {
             JOIN(c);
             HIP_TRY(c, wf_launch_step(c->fam, a, kn, c->stream, c->num_cus));
@@ -1108,9 +1124,12 @@ const char *wf_call_kernel_name(const wf_ctx *c, int n_steps)
 {
     if (!c || n_steps < 1) return "none";
     if (n_steps == 1 || c->fam != WF_FAM_WAVE || c->p.wind_mode != WF_WIND_CALM) return wf_step_kernel_name(c);
+    // (a call WITH actions: one without may go to wf_step_ticks where this one does not, see ticks_serves_split)
     const bool sp = splits(c, 1);
-    const bool in_kernel = sp ? multi_rows_call(c, n_steps) : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps));
-    if (!in_kernel) return sp ? wf_step_kernel_name(c) : (c->knobs.fused_legacy ? "wf_step_wave (fused ticks, one environment per wave)" : "wf_step_ticks (fused ticks, one environment per wave, packed cells)");
+    const bool rows_loop = sp && multi_rows_call(c, n_steps);
+    const bool ticks = sp && ticks_serves_split(c, true, rows_loop);
+    const bool in_kernel = !ticks && (sp ? rows_loop : ((c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps)));
+    if (!in_kernel) return sp && !ticks ? wf_step_kernel_name(c) : (c->knobs.fused_legacy ? "wf_step_wave (fused ticks, one environment per wave)" : "wf_step_ticks (fused ticks, one environment per wave, packed cells)");
     WfArgs a = base_args(c);
     a.n_steps = n_steps;
     if (sp) {
@@ -1128,7 +1147,9 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
     if (n_steps == 1) return per_step;
     if (c->p.wind_mode != WF_WIND_CALM) return per_step * n_steps;                      // wind: single-step launches only
     if (!splits(c, 1)) return 1;                                                        // one (fused) launch
-    return multi_rows_call(c, n_steps) ? c->n_parts : c->n_parts * n_steps;
+    const bool rows_loop = multi_rows_call(c, n_steps);
+    if (ticks_serves_split(c, true, rows_loop)) return 1;                               // (a call with actions, as above)
+    return rows_loop ? c->n_parts : c->n_parts * n_steps;
 }
 
 #ifdef WF_WAVE_TIMING

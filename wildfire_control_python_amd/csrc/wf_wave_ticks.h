@@ -41,8 +41,11 @@ __device__ __forceinline__ uint32_t nz32(uint32_t v)
     return r;
 }
 
+#ifndef WF_TICKS_LB
+#define WF_TICKS_LB 6   // waves per SIMD the register allocator must leave room for (8: 80 scalar registers, 145 of them spilled, 22 vector registers in scratch)
+#endif
 template <int W, int H, bool RARE>
-__global__ __launch_bounds__(256, WF_LB) void wf_step_ticks(const WfArgs a)
+__global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a)
 {
     constexpr int CELLS = W * H, LANES = CELLS / 4;
     constexpr uint32_t ENV_BYTES = CELLS * 4;
