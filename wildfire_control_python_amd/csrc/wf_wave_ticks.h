@@ -104,12 +104,14 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
         bool dirty = false;
         // am bit j = cell j of this lane is the agent's cell (a per-lane register: "is the agent standing on fire" is one
         // AND against the lane's burning bits instead of a four-way select on the scalar unit)
-        uint32_t am = 0;
-        auto place_agent = [&]() {
+        // watch = that cell can burn under the agent at all (grass or fire: an agent that digs stands on dirt, and the test is skipped)
+        uint32_t am = 0, watch = 1;
+        auto place_agent = [&](const uint32_t type_under) {
             const uint32_t qn = ay * W + ax;
             am = lane == (qn >> 2) ? 1u << (qn & 3u) : 0u;
+            watch = RARE ? 1u : ((1u << WF_GRASS | 1u << WF_FIRE) >> min(type_under, 31u)) & 1u;
         };
-        place_agent();
+        place_agent(cell_type_at(c, ay * W + ax));
 
         // No memory operation per step: the actions of a block of 16 steps come in with one load (lane k = step k of the
         // block), its rewards / done flags collect in lanes 0..15 of three registers and leave with one store each.
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                     constexpr int j = decltype(J)::value;
                     RB[j] = CM<W, H, j>::VALID & ~(((qs & 3u) == (uint32_t)j) ? (1ull << (qs >> 2)) : 0ull);
                 });
-                place_agent();
+                place_agent((uint32_t)WF_DIRT);              // Agent.__init__ digs its spawn cell (:111-113)
                 dirty = true;
                 put(slot, 0.0, 0u);
                 return 1u;
@@ -176,6 +178,12 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
             if constexpr (ACT) {
                 vact = 0xffu;
                 if (lane < bn) vact = (uint32_t)(uint8_t)a.actions[(b0 + lane) * stride + e];
+            }
+            {   // every step of the block: the default reward, not done - unless its step says otherwise
+                const u64 dbits = (u64)__double_as_longlong(a.default_reward);
+                vr_lo = (uint32_t)dbits;
+                vr_hi = (uint32_t)(dbits >> 32);
+                vdone = 0;
             }
             uint32_t k = 0;
             if (__builtin_expect(!(fl & WF_F_RUNNING), 0)) k = finished(0u, bn);
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                         c[1] ^= kk == 1u ? dl : 0u;
                         c[2] ^= kk == 2u ? dl : 0u;
                         c[3] ^= kk == 3u ? dl : 0u;
-                        place_agent();
+                        place_agent(dug ? (uint32_t)WF_DIRT : moved ? td : tcur);
                     }
                     // Verdict: can this dig change which cells reach the border?  (exact component count on the ring
                     // and the border refinement: see group_phase_a)
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                     c[j] = pk_add_u16(c[j], lanebit(F) ? d : 0u);
                 }
                 {   // :87 drop dead agents (Agent.is_dead environment.py:116-120): dead, or standing on a burning cell
-                    if constexpr (!RARE) {
+                    if (!RARE && __builtin_expect(watch, 0)) {
                         // without the rare codes "burning" is "type fire": the lane's burning bits (one add-with-carry
                         // per component: x = 2x + bit) against the agent's bit
                         uint32_t fb = lanebit(FR[3]) ? 1u : 0u;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                         onfire = nz64(__ballot((fb & am) != 0u));
                     }
                     const uint32_t dies = upd & fl & ((fl >> 3) | onfire) & 1u;    // alive & (dead | on fire)
-                    fl &= ~(dies * (uint32_t)(WF_F_ALIVE | WF_F_VISIBLE));
+                    fl &= ~(dies | (dies << 1));                                   // WF_F_ALIVE | WF_F_VISIBLE (no multiply: it would go through the vector unit)
                 }
                 uint32_t ign_bits = 0;
                 static_for<4>([&](auto J) {
@@ -345,9 +353,10 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                     contained = nz64(hit) ^ 1u;
                     fl |= contained << 6;                                          // :361-367
                 }
-                double reward = a.default_reward;                                  // :390
-                // anything but "-1, not done": burnt out, agent dead, contained (rare)
+                // anything but "the default reward (:390), not done" - what the block's registers were pre-set to -: burnt out,
+                // agent dead, contained (rare)
                 if (__builtin_expect(((anyfire & fl) ^ 1u) | contained, 0)) {
+                    double reward = a.default_reward;
                     if (!anyfire) {                                                // :384-387 burnt out
                         int healthy = 0;
 #pragma unroll
@@ -356,8 +365,8 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                     }
                     reward = (fl & WF_F_ALIVE) ? reward : a.death_penalty;         // :380-381
                     reward = rfl_f64(contained ? a.contained_bonus : reward);
+                    put(k, reward, ((fl >> 4) & 1u) ^ 1u);                         // done: forest_fire.py:48
                 }
-                put(k, reward, ((fl >> 4) & 1u) ^ 1u);                             // done: forest_fire.py:48
                 if (__builtin_expect(!(fl & WF_F_RUNNING), 0)) {                   // the episode ended with this step
                     if (k + 1u < bn) k += finished(k + 1u, bn);
                 }
