@@ -25,6 +25,8 @@ RUNS = [  # (directory, what was run)
     ("kt_c4_single", "WF_NO_SPLIT=1, same command   (BASELINE configs[3], one launch sequence per step: the per-kernel durations add up to the step)"),
     ("kt_hbm_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline --batch 1048576 --steps 120 --warmup 20"
                       "   (1 048 576 x 14x14 = 822 MB of state: true HBM streaming, one launch per step)"),
+    ("kt_c2", "python3 bench.py --no-cpu-baseline --legs c2 --steps 100 --warmup 10 --fused 0   (the wf_step_ticks rows: BASELINE configs[1], "
+              "4 096 x 10x10, no-op, one launch = 16 ticks; the other rows are the headline loop of the same run)"),
 ]
 
 
@@ -57,7 +59,8 @@ lines, vals = [], {}
 for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
                         ("c4", "wf_step_tiled", "1 024 x 256x256 (268 MB; WF_NO_SPLIT=1, ticks 60..120 after the reset, --min-ms 0)"),
                         ("hbm", "wf_step_rows", "1 048 576 x 14x14 (822 MB; WF_NO_SPLIT=1, steps 60..100, --min-ms 0)"),
-                        ("c5", "wf_step_rows", "125 000 x 14x14 (98 MB, one shard of configs[4]; WF_NO_SPLIT=1, --steps 40 --warmup 400)")):
+                        ("c5", "wf_step_rows", "125 000 x 14x14 (98 MB, one shard of configs[4]; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
+                        ("c2", "wf_step_ticks", "4 096 x 10x10, no-op, 16 ticks per launch (1.6 MB; the c2 leg of a default bench run; per LAUNCH = per 16 ticks)")):
     lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
     for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
         if not os.path.isdir(d):
@@ -99,10 +102,13 @@ t["other_sizes"] = {
     "hbm_1m": traffic("hbm", "wf_step_rows<14,14,2,false>", 1048576 * 196, "1048576 x 14x14, bench inputs (822 MB: true HBM streaming)"),
 }
 t["other_sizes"]["c5_shard"] = traffic("c5", "wf_step_rows<14,14,2,false>", 125000 * 196, "125000 x 14x14, bench inputs (98 MB: one shard of BASELINE configs[4])")
+t["other_sizes"]["c2"] = traffic("c2", "wf_step_ticks<10,10,false>", 4096 * 100, "4096 x 10x10, no-op, 16 ticks per launch (BASELINE configs[1]); the grid "
+                                 "stays in registers between the ticks, so a launch moves the state once: compare with state_bytes, not with the 16 ticks' algorithmic bytes")
+t["other_sizes"]["c2"]["algorithmic_bytes_per_launch"] = 4096 * 100 * 8 * 16
 # what bench.py looks up, per leg of its JSON line; every entry names the PMC pass it came from
 t["kernel_source_sha256"] = open(f"{src}/kernel_source_sha256.txt").read().strip()
 t["legs"] = {}
-for leg, key, cfg in (("c3", None, "c3"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5")):
+for leg, key, cfg in (("c3", None, "c3"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5"), ("c2", "c2", "c2")):
     e = dict(t if key is None else t["other_sizes"][key])
     for k in ("other_sizes", "legs", "note", "round", "kernel_source_sha256"):
         e.pop(k, None)
