@@ -1031,7 +1031,7 @@ static int host_step(wf_ctx *c, const int8_t *actions, int n_steps, uint64_t upd
             HIP_TRY(c, wf_launch_copy_words(c->v_out + lo, c->p_out + lo, (hi - lo + 3) & ~(size_t)3, c->stream));
         }
     } else {
-        // small batch: the kernels read the actions from and write reward / done to pinned host memory themselves
+        // the kernels read the actions from and write reward / done to pinned host memory themselves
         rc = wf_step_obs_device(c, actions ? c->d_actions : nullptr, n_steps, update_mask, reward ? p_reward : nullptr, done ? p_done : nullptr, obs_dst);
         if (rc != WF_OK) return rc;
         JOIN(c);

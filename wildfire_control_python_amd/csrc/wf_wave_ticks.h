@@ -10,7 +10,9 @@
 // agent's position, the flags word, the reward and the reachability board are wave-uniform: they live in scalar
 // registers here, the agent reads the few cell types it needs with one ds_bpermute (ring + destination + own cell), and
 // the vector unit only does the tick on the packed words (the formulation of wf_step_group's phase B).  BASELINE
-// configs[1] (4 096 x 10x10, 16 ticks per call) is bound by vector instruction issue at four waves per SIMD.
+// configs[1] (4 096 x 10x10, 16 ticks per call: four waves per SIMD) is bound by instruction issue - 72 vector + 84 scalar
+// instructions per tick in the no-action loop, and the scalar unit issues one instruction per cycle for the four SIMDs
+// of a CU, i.e. a SIMD gets a scalar slot as often as a vector slot: scalar instructions are not free.
 
 // type byte of cell q (wave-uniform q) of the packed grid c
 __device__ __forceinline__ uint32_t cell_type_at(const uint32_t (&c)[4], uint32_t q)
@@ -248,8 +250,9 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                         place_agent(dug ? (uint32_t)WF_DIRT : moved ? td : tcur);
                     }
                     // Verdict: can this dig change which cells reach the border?  (exact component count on the ring
-                    // and the border refinement: see group_phase_a)
-                    {
+                    // and the border refinement: see group_phase_a.)  Nobody asks once the fire has touched the border or
+                    // the bonus is paid - the containment test is over for the episode (environment.py:345-346).
+                    if (dug & (nz32((fl | nocont) & (uint32_t)(WF_F_BORDER | WF_F_CONTAINED)) ^ 1u)) {
                         const uint32_t x0 = xd == 0u ? 1u : 0u, xl = xd == (uint32_t)(W - 1) ? 1u : 0u;
                         const uint32_t y0 = yd == 0u ? 1u : 0u, yl = yd == (uint32_t)(H - 1) ? 1u : 0u;
                         const uint32_t ex = x0 | xl, ey = y0 | yl;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
                         const uint32_t comps = (uint32_t)__popc(even) - (uint32_t)__popc(eff);
                         const uint32_t local_fail = (comps + 0x7FFFFFFEu) >> 31;          // comps >= 2 (comps in 0..4)
                         const uint32_t border_fail = onb & min(even, 1u) & (min(ring & bnmask, 1u) ^ 1u);
-                        ringflag = dug & (local_fail | border_fail | min(zring & 0x55u, 1u)) & 1u;
+                        ringflag = (local_fail | border_fail | min(zring & 0x55u, 1u)) & 1u;
                     }
                 }
 
