@@ -18,12 +18,15 @@
 //     shifts (neighbour q+-1 / q+-W of component j lives at a fixed (lane offset,
 //     component) pair known at compile time) and are read back per lane with
 //     v_cndmask on the mask.  No LDS allocation, no barrier, no per-cell index math.
-//   * work split: the scalar unit (one instruction per clock for the whole CU) does
-//     ONLY the 64-bit mask algebra and the rare uniform branches; the per-cell rule
-//     and the per-environment flag logic (agent move/dig/death, RUNNING, reward)
-//     run on the vector unit, the latter branch-free on values that are identical
-//     in all 64 lanes.  Row-wrap and border tests use per-lane VGPR constants, not
-//     64-bit scalar constants.
+//   * work split: the scalar unit (one instruction per clock for the whole CU: a SIMD
+//     gets a scalar slot as often as a vector slot) does the 64-bit mask algebra and
+//     the rare uniform branches; the per-cell rule runs on the vector unit.  The
+//     per-environment logic (agent move/dig/death, RUNNING, reward) runs where it
+//     has the most lanes to fill: lanes = environments in the single-step kernels
+//     (wf_step_group / wf_step_rows, phases A and C), the scalar unit in the n-step
+//     kernel of one environment per wave (wf_step_ticks); round 1's wf_step_wave ran
+//     it on the vector unit with 64 identical lanes.  Row-wrap and border tests use
+//     per-lane VGPR constants, not 64-bit scalar constants.
 //   * rarely needed parameters live in device memory (WfCold) and every rare branch
 //     pins its inputs, so the optimiser cannot speculate rare-path work (or its
 //     scalar registers) onto the hot path.
@@ -650,7 +653,7 @@ int wf_split_align(int W, int H, const WfKnobs &k)
 const char *wf_family_name(WfFamily f, int, int)
 {
     switch (f) {
-    case WF_FAM_WAVE: return "wf_step_rows/wf_step_group/wf_step_wave (whole grids in a wave's registers, CA core on ballot bitboards; env logic lane-parallel)";
+    case WF_FAM_WAVE: return "wf_step_rows/wf_step_group/wf_step_ticks (whole grids in a wave's registers, CA core on ballot bitboards; env logic lane-parallel or scalar)";
     case WF_FAM_TILED: return "wf_step_tiled (16-row strips per wave, ballot row masks, LDS-staged strip halos)";
     case WF_FAM_CELLS: return "wf_step_env / wf_step_cells (generic: a wave or a workgroup per environment; thread-per-cell for a few huge grids)";
     default: return "none";

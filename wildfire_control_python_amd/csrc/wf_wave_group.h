@@ -15,7 +15,8 @@
 //      in memory, no unpack/pack): the CA tick proper with ballot masks.
 //   C  lanes = environments again: flags, reward, done, records.
 // Per environment this costs ~75 vector + ~85 scalar instructions against ~310 + ~140
-// for the one-env-per-wave formulation (which remains the fused multi-step path).
+// for round 1's one-environment-per-wave formulation (wf_step_wave; the n-step path has since moved
+// to wf_step_ticks, which keeps this phase B and puts the per-environment logic on the scalar unit).
 enum {
     PB_RUNNING = 1, PB_PRECHECK = 2, PB_VALID = 4, PB_RING = 8,       // phase A -> B (per env)
     RB_ANYFIRE = 1, RB_BORDER = 2, RB_CONTAINED = 4, RB_RECOMPUTED = 8, RB_WASRESET = 16, RB_HEALTHY_SHIFT = 8
