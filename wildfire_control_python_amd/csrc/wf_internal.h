@@ -118,6 +118,8 @@ bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int 
 const char *wf_multi_step_kernel(const WfArgs &a, const WfKnobs &k, int num_cus);
 hipError_t wf_launch_step(WfFamily fam, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus);
 hipError_t wf_launch_reset(WfFamily fam, const WfArgs &a, hipStream_t s, int num_cus);
+// the n-step kernels of one environment per wave (wf_step_ticks; wf_kernels.hip built with -DWF_TU=1)
+hipError_t wf_launch_nstep_wave(const WfArgs &a, const WfKnobs &k, hipStream_t s, int blocks);
 // big-grid families (wf_tiled.hip, wf_generic.hip): one step = pre / (auto-reset) / tiles / post; planes -> planes_out
 // halo != nullptr (tiled family): the step runs IN PLACE (planes_out == planes); halo = u64[batch][gx][8] scratch
 // generic family's part of wf_launch_step_big (wf_generic.hip)

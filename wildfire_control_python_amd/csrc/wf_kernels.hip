@@ -257,8 +257,44 @@ __device__ __forceinline__ void emit_obs(uint8_t *lds, int8_t *obs_e, const uint
     }
 }
 
+#ifndef WF_WAVE_SHAPES   // (a kernel experiment may build one shape only: -D'WF_WAVE_SHAPES(X)=X(10,10)')
+#define WF_WAVE_SHAPES(X) X(8, 8) X(10, 10) X(12, 12) X(14, 14) X(16, 16) X(16, 8) X(8, 16) X(20, 10) X(10, 20)
+#endif
+
 #include "wf_wave_fused.h"   // wf_step_wave: n fused steps, one environment per wave (round-1 formulation, WF_FUSED_LEGACY=1)
 #include "wf_wave_ticks.h"   // wf_step_ticks: n fused steps, one environment per wave, packed cells + scalar agent
+
+// This file is built as TWO translation units so that its halves compile in parallel (the Makefile passes -DWF_TU=1 for
+// the second): WF_TU == 1 holds the n-step kernels of one environment per wave and their launcher, WF_TU == 0 everything else.
+#ifndef WF_TU
+#define WF_TU 0
+#endif
+#if WF_TU == 1
+
+}  // namespace
+
+hipError_t wf_launch_nstep_wave(const WfArgs &a, const WfKnobs &k, hipStream_t s, int blocks)
+{
+    // dig toggle / rivers (off in the reference's defaults) run in their own instantiations of the step kernels
+    const bool rare = (a.hot_flags & WF_HOT_RARE) != 0;
+#define X(w, h)                                                                                                          \
+    if (a.W == w && a.H == h) {                                                                                          \
+        if (k.fused_legacy) {                                                                                            \
+            if (rare) hipLaunchKernelGGL((wf_step_wave<w, h, true, true>), dim3(blocks), dim3(256), 0, s, a);            \
+            else hipLaunchKernelGGL((wf_step_wave<w, h, true, false>), dim3(blocks), dim3(256), 0, s, a);                \
+        } else {                                                                                                         \
+            if (rare) hipLaunchKernelGGL((wf_step_ticks<w, h, true>), dim3(blocks), dim3(256), 0, s, a);                 \
+            else hipLaunchKernelGGL((wf_step_ticks<w, h, false>), dim3(blocks), dim3(256), 0, s, a);                     \
+        }                                                                                                                \
+        return hipGetLastError();                                                                                        \
+    }
+    WF_WAVE_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+#else   // WF_TU == 0
+
 #include "wf_wave_group.h"   // wf_step_group + phases A / C
 #include "wf_wave_rows.h"    // wf_step_rows
 
@@ -524,13 +560,7 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         hipLaunchKernelGGL((wf_reset_wave<W, H>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.n_steps > 1 && !k.multi_rows) {
         if (a.hot_flags & WF_HOT_WIND) return hipErrorInvalidValue;     // (wind: the host issues n single-step launches)
-        if (k.fused_legacy) {
-            if (rare) hipLaunchKernelGGL((wf_step_wave<W, H, true, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((wf_step_wave<W, H, true, false>), dim3(blocks), dim3(256), 0, s, a);
-        } else {
-            if (rare) hipLaunchKernelGGL((wf_step_ticks<W, H, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((wf_step_ticks<W, H, false>), dim3(blocks), dim3(256), 0, s, a);
-        }
+        return wf_launch_nstep_wave(a, k, s, blocks);                   // wf_step_ticks (the file's other translation unit)
     } else {
         const StepPlan p = plan_single<W, H>(a, k, num_cus);
         if (a.n_steps > 1 && p.kind != STEP_ROWS) return hipErrorInvalidValue;   // only the rows kernel has the step loop
@@ -568,9 +598,6 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
     return hipGetLastError();
 }
 
-#ifndef WF_WAVE_SHAPES   // (a kernel experiment may build one shape only: -D'WF_WAVE_SHAPES(X)=X(10,10)')
-#define WF_WAVE_SHAPES(X) X(8, 8) X(10, 10) X(12, 12) X(14, 14) X(16, 16) X(16, 8) X(8, 16) X(20, 10) X(10, 20)
-#endif
 
 hipError_t dispatch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_t s, int num_cus)
 {
@@ -794,3 +821,5 @@ hipError_t wf_launch_get_state(const uint32_t *planes, int8_t *obs, int batch, i
     hipLaunchKernelGGL(wf_get_state_kernel, dim3((unsigned)blocks), dim3(256), 0, s, planes, obs, batch, H, W);
     return hipGetLastError();
 }
+
+#endif   // WF_TU
