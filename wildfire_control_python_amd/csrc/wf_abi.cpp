@@ -63,6 +63,7 @@ struct wf_ctx {
     int8_t *v_actions = nullptr;
     uint8_t *v_out = nullptr;          // [n doubles of reward][n bytes of done]
     uint8_t *p_out = nullptr;          // pinned host block of the same layout
+    uint32_t sweeps = 0;               // big-grid steps issued so far (WF_SWEEP_ALT: odd ones walk the batch backwards)
     uint32_t *p_flag = nullptr;        // pinned completion word of synchronous calls (WF_FLAG_WAIT)
     uint32_t flag_seq = 0;
     size_t v_count = 0;                // n the mirrors were sized for
@@ -895,6 +896,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             a.done = d_done ? d_done + off + lo : nullptr;
             a.n_steps = 1;
             a.update_mask = (update_mask >> st) & 1ull;
+            a.sweep_rev = c->knobs.sweep_alt ? (int32_t)(c->sweeps & 1u) : 0;
             // World.get_state() of the final state: written by the tiled step kernel itself where the shape allows,
             // else by the observation kernel behind it - on the share's own stream either way (no join for it)
             const bool want_obs = d_obs && st == n_steps - 1;
@@ -908,6 +910,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
                 HIP_TRY(c, wf_launch_get_state(a.planes_out, d_obs + (size_t)lo * cells * 3, hi - lo, c->H, c->W, si));
         }
         if (c->planes_alt) { uint32_t *t = c->planes; c->planes = c->planes_alt; c->planes_alt = t; }   // ping-pong
+        ++c->sweeps;
     }
     if (split) c->side_pending = true;
     return WF_OK;

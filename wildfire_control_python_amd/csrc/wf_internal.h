@@ -56,7 +56,7 @@ struct WfArgs {
     int32_t group;           // single-step group kernel: environments per wave
     uint32_t env_base;       // index of this launch's env 0 inside the context (split launches)
     int32_t step_stride;     // environments in the whole context = row length of the (n_steps, batch) action / reward / done arrays
-    int32_t pad1;
+    int32_t sweep_rev;       // big-grid families: this step walks the batch from its far end (see WfKnobs::sweep_alt)
     double default_reward, death_penalty, contained_bonus;
 };
 
@@ -75,6 +75,8 @@ struct WfKnobs {
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
     int host_stage_mode; // WF_HOST_STAGE_MODE: 1 actions through a device mirror, 2 reward / done, 3 both (default of the experiment)
+    int sweep_alt;       // WF_SWEEP_ALT (default 1): the tiled step kernels walk the batch forwards and backwards in turn, so that a step
+                         // starts on the bytes the step before touched last (still in the Infinity Cache); 0 = always forwards
     int fused_legacy;    // WF_FUSED_LEGACY: n-step calls of one environment per wave on wf_step_wave (unpacked cells, agent logic on the vector unit) instead of wf_step_ticks
     int flag_wait;       // WF_FLAG_WAIT: synchronous host-buffer calls wait on a flag a one-lane kernel writes to pinned memory (us of spinning; 0 = hipStreamSynchronize)
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)

@@ -644,6 +644,7 @@ void wf_read_knobs(WfKnobs *k)
     k->host_stage_min = num("WF_HOST_STAGE_MIN", 0);
     k->flag_wait = num("WF_FLAG_WAIT", 0);
     k->fused_legacy = set("WF_FUSED_LEGACY");
+    k->sweep_alt = num("WF_SWEEP_ALT", 1);     // (1 024 x 256x256: 82 against 86 us per step; tools/sweep_alt.sh)
     k->host_stage_mode = num("WF_HOST_STAGE_MODE", 0);
     k->multi_rows = 0;
 }

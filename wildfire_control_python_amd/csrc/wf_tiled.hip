@@ -238,8 +238,10 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const uint32_t wv = rfl(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
     const uint32_t gx = (H + nw * WR - 1u) / (nw * WR);          // workgroups per environment
-    const uint32_t e = blockIdx.x / gx;
-    const uint32_t r0 = ((blockIdx.x % gx) * nw + wv) * WR;      // segment 0's first row; segment s: r0 + 16 s
+    // (workgroups are dispatched in blockIdx order: a reversed step walks the batch from its far end)
+    const uint32_t bid = a.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const uint32_t e = bid / gx;
+    const uint32_t r0 = ((bid % gx) * nw + wv) * WR;             // segment 0's first row; segment s: r0 + 16 s
     const uint32_t r1 = min(r0 + TR, H);                         // end of the sweep (segment 0's rows)
     const bool has_rows = r0 < H;
     Pack<P> pk;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const uint32_t lane_cell0 = pk.row_off * LW + pk.ql;         // this lane's quad index at sweep position 0 (+ r * LW)
     const uint32_t ign = (uint32_t)a.ignite_count;
     const uint32_t md = mode[e];
-    const uint32_t wg_row0 = (blockIdx.x % gx) * nw * WR;
+    const uint32_t wg_row0 = (bid % gx) * nw * WR;
     const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
     int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
     if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
@@ -331,14 +333,14 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     if (r0 > 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u64 v = wv > 0 ? (halo[wv - 1][1][j] >> (LWP * (uint32_t)(P - 1))) : outer[(size_t)blockIdx.x * 8 + j];
+            const u64 v = wv > 0 ? (halo[wv - 1][1][j] >> (LWP * (uint32_t)(P - 1))) : outer[(size_t)bid * 8 + j];
             Sp[j] = (((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0;
         }
     }
     if (r0 + WR < H) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u64 v = wv + 1u < nw ? halo[wv + 1][0][j] : outer[(size_t)blockIdx.x * 8 + 4 + j];
+            const u64 v = wv + 1u < nw ? halo[wv + 1][0][j] : outer[(size_t)bid * 8 + 4 + j];
             Sb[j] = ((((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0) << (LWP * (uint32_t)(P - 1));
         }
     }
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
     extern __shared__ u64 lds[];                     // flood: [H*4] pass, [H*4] reach
     __shared__ u64 pm[4][8][4];                      // flood: the interleaved passable masks of a wave's current 8 rows
     __shared__ uint32_t s_mode, changed;
-    const uint32_t e = blockIdx.x;
+    const uint32_t e = a.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2, words = H * 4u;
     const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
     uint4 ev;
