@@ -19,3 +19,12 @@ BATCH=9000 SIZE=14 run w14split OPTIONS=wind,rivers
 BATCH=9000 SIZE=14 run w14multi OPTIONS=wind STEPS_PER_CALL=4
 BATCH=9000 SIZE=10 run r10multi OPTIONS=rivers STEPS_PER_CALL=6
 BATCH=9000 SIZE=10 run r10res OPTIONS=rivers,toggle STEPS_PER_CALL=6 WF_RESIDENT=1
+# tiled family (every other step walks the batch backwards: WF_SWEEP_ALT, default on) and n-step calls on wf_step_ticks
+STEPS=300
+BATCH=600 SIZE=64 run t64 OPTIONS=rivers,toggle
+BATCH=130 SIZE=128 run t128 OPTIONS=rivers
+BATCH=130 SIZE=128 run t128fwd OPTIONS=rivers WF_SWEEP_ALT=0
+STEPS=640
+BATCH=4001 SIZE=10 run k10 OPTIONS=rivers,toggle STEPS_PER_CALL=7
+BATCH=3000 SIZE=14 run k14 STEPS_PER_CALL=33
+BATCH=8000 SIZE=16 run k16 STEPS_PER_CALL=16
