@@ -371,6 +371,12 @@ def main():
         barrier()
         return time.perf_counter() - t0, ev
 
+    # Everything the setup allocated (torch, numpy, ctypes) moves to the permanent generation: a full collection of the
+    # cyclic garbage collector over those objects takes ~40 ms, and one landing inside a host-side timing loop (29 calls of
+    # 50 us) turned BENCH_r03's lent-buffer figure into 1 400 us per step (round 4: per-call times in gpurun_out/r4/).
+    import gc
+    gc.collect()
+    gc.freeze()
     stepper.run(0, Wm)
     env.sync()
     wall, ev_ms = timed_region(Wm, K)
@@ -450,21 +456,30 @@ def main():
     if world == 1 and not args.no_extras:
         a_np = make_actions(30, lo, lo + B, args.seed + 2)
         env.step_many(a_np[0])
-        th = time.perf_counter()
+        t_own = []
         for s in range(1, 30):
+            t0 = time.perf_counter()
             env.step_many(a_np[s])
-        th = time.perf_counter() - th
+            t_own.append(time.perf_counter() - t0)
+        th = sum(t_own)
         # the same with the pinned buffers the library lends (wf_host_staging): no host copies of actions / reward / done
         l_act, _, _ = env.host_staging(1)
         l_act[0] = a_np[0]
         env.step_many(l_act, borrow=True)
-        tl = time.perf_counter()
+        t_lent = []
         for s in range(1, 30):
+            t0 = time.perf_counter()
             l_act[0] = a_np[s]
             env.step_many(l_act, borrow=True)
-        tl = time.perf_counter() - tl
+            t_lent.append(time.perf_counter() - t0)
+        tl = sum(t_lent)
+        if os.environ.get("WF_BENCH_DEBUG"):
+            print("host_api per call us: own", [round(x * 1e6) for x in t_own], "lent", [round(x * 1e6) for x in t_lent], file=sys.stderr)
+        med = lambda v: sorted(v)[len(v) // 2]
         host_api = {"cell_updates_per_s": cells * 29 / th, "us_per_step": th / 29 * 1e6,
                     "lent_buffers_us_per_step": tl / 29 * 1e6, "lent_buffers_cell_updates_per_s": cells * 29 / tl,
+                    "median_us_per_step": med(t_own) * 1e6, "max_us_per_step": max(t_own) * 1e6,
+                    "lent_buffers_median_us_per_step": med(t_lent) * 1e6, "lent_buffers_max_us_per_step": max(t_lent) * 1e6,
                     "note": "wf_step(): numpy in / out, PCIe and host synchronisation included (the kernels read actions from and write "
                             "reward / done to pinned host memory); lent_buffers = the same call on the pinned buffers wf_host_staging lends: "
                             "no host copies.  Never `value`: large batches belong on the device API"}

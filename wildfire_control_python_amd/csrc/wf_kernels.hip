@@ -535,7 +535,7 @@ StepPlan plan_single(const WfArgs &a, const WfKnobs &k, int num_cus)
     }
     // (the workgroup-shared experiment exists for the reference's default options only)
     const bool wind = (a.hot_flags & WF_HOT_WIND) != 0;      // wind with a direction: the group layout's WIND instantiation
-    const bool shared = k.shared && (p.G == 8 || p.G == 16) && a.batch >= 4096 && !(a.hot_flags & WF_HOT_RARE) && !wind;
+    const bool shared = k.shared && (p.G == 2 || p.G == 4 || p.G == 8 || p.G == 16) && a.batch >= 4096 && !(a.hot_flags & WF_HOT_RARE) && !wind;
     p.kind = shared ? STEP_GROUP_SHARED : STEP_GROUP;
     if (wind) return p;
     if constexpr (HasRows<W, H>::value) {

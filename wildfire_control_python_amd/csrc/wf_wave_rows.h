@@ -479,6 +479,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                         chg |= dd;
                     }
                     u64 IGNANY = 0, IGN0 = 0, IGNL = 0;
+#ifdef WF_EXP_SKIP_HEAT      // timing experiment only (wrong results): the heat / ignition pass left out - is the kernel bound by instruction issue?
+                    static_for<CPL>([&](auto J) { constexpr int j = decltype(J)::value; FIREALL |= STILL[j]; HITS |= STILL[j] & RBG[j]; });
+                    if (false)
+#endif
                     static_for<CPL>([&](auto J) {
                         constexpr int j = decltype(J)::value;
                         // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294): burning neighbours
@@ -496,6 +500,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                         c[j] = addc(c[j], add, IGN);                                   // grass -> fire: +1 through the carry-in
                         chg |= add;                                                    // (an ignition always comes with heat)
                         IGNANY |= IGN;
+#ifdef WF_EXP_EXTRA_VALU     // timing experiment: WF_EXP_EXTRA_VALU extra vector compares per cell slot (results unused, state unchanged)
+#pragma unroll
+                        for (int x = 0; x < WF_EXP_EXTRA_VALU; ++x) { u64 dm; asm volatile("v_cmp_eq_u32_e64 %0, %1, %1" : "=s"(dm) : "v"(c[j])); }
+#endif
                         if constexpr (j == 0) IGN0 = IGN;
                         if constexpr (j == CPL - 1) IGNL = IGN;
                         const u64 FJ = STILL[j] | IGN;
