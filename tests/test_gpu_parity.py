@@ -1088,10 +1088,11 @@ def test_full_size_properties_65536x14x14(wf):
 # ------------------------------------------------- BASELINE configs at their stated sizes
 def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
     """BASELINE configs[1] exactly: 4 096 batched 10x10 grids, random fuel U{10..40}, no agent action, 16 ticks per
-    call (one fused launch, grids in registers between ticks): whole state, rewards and done flags vs the oracle."""
+    call (fused ticks, grids in registers between ticks; since round 4 as four part launches of wf_step_ticks on the
+    context's streams): whole state, rewards and done flags vs the oracle."""
     B, S, n = 4096, 10, 16
     env = wf.BatchedForestFire(B, size=S, seed=1234, fuel_range=(10, 40))
-    assert env._lib.wf_call_launches(env._h, n) == 1
+    assert env._lib.wf_call_launches(env._h, n) == 4
     env.reset(seed=1234)
     op = O.default_params(fuel_lo=10, fuel_hi=40)
     planes, envs = O.new_state(B, S, S)
@@ -2049,7 +2050,7 @@ def test_n_step_calls_of_split_contexts_on_the_one_wave_kernel(wf, monkeypatch, 
     env = wf.BatchedForestFire(B, width=W, height=H, seed=41, auto_reset=True, containment=True, fuel_range=(2, 6))
     assert env.step_launches == 2
     rows = env.step_kernel.startswith("wf_step_rows")
-    assert env._lib.wf_call_launches(env._h, 8) == (2 if rows else 1)      # (the introspection speaks of calls with actions)
+    assert env._lib.wf_call_launches(env._h, 8) == (2 if rows else 4)      # (the introspection speaks of calls with actions; wf_step_ticks: four parts)
     assert rows == noop
     env.reset(seed=41)
     op = O.default_params(containment=1, fuel_lo=2, fuel_hi=6)
@@ -2081,6 +2082,63 @@ def test_n_step_calls_of_split_contexts_on_the_one_wave_kernel(wf, monkeypatch, 
         np.testing.assert_array_equal(gp, planes, err_msg=f"call {call}: planes")
         np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"call {call}: envs")
     assert resets > B // 2
+    env.close()
+
+
+@pytest.mark.parametrize("W,H,B,split", [(10, 10, 8192 + 70, None), (14, 14, 4096 + 3, None), (10, 10, 2048 + 9, None), (8, 8, 9000, "3")])
+def test_device_calls_with_changing_part_counts(wf, monkeypatch, W, H, B, split):
+    """Asynchronous device-API calls on the context's own streams: single steps of a large batch go out as two part launches,
+    n-step calls without actions as two or four wf_step_ticks launches (round 4) - another cut of the batch over the streams,
+    so a call with another number of parts must wait for everything the call before it put on any stream.  Groups of calls
+    of both kinds go out back to back, without a synchronisation in between; then the state and every call's outputs are
+    checked against the oracle."""
+    import torch
+    for k in ("WF_FUSED_LEGACY", "WF_MULTI_SMALL", "WF_NO_MULTI", "WF_GROUP", "WF_NO_SPLIT", "WF_SPLIT", "WF_TICKS_SPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    if split:
+        monkeypatch.setenv("WF_SPLIT", split)
+    env = wf.BatchedForestFire(B, width=W, height=H, seed=43, auto_reset=True, containment=True, fuel_range=(2, 6))
+    monkeypatch.delenv("WF_SPLIT", raising=False)
+    want = int(split) if split else (4 if B >= 4096 else 2)
+    if env.step_launches > 1 and env.step_kernel.startswith("wf_step_rows"):
+        want = env.step_launches      # (the introspection speaks of calls WITH actions: the rows kernel's step loop, one launch per part)
+    assert env._lib.wf_call_launches(env._h, 8) == want, env._lib.wf_call_launches(env._h, 8)
+    env.reset(seed=43)
+    op = O.default_params(containment=1, fuel_lo=2, fuel_hi=6)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=43, params=op)
+    rng = np.random.default_rng(W + B)
+    dev = torch.device("cuda", 0)
+    resets = 0
+    schedule = ((8, 1, 1), (16, 1, 5), (5, 1, 1, 1, 12), (1, 3), (7,))
+    for g, group in enumerate(schedule):
+        issued = []
+        for n in group:                                  # the whole group goes out without a synchronisation in between
+            acts = None if n > 1 else rng.integers(0, 5, size=(1, B)).astype(np.int8)
+            outs = []
+            for k in range(n):
+                stopped = (envs["flags"] & O.F_RUNNING) == 0
+                ro, do = O.step(planes, envs, None if acts is None else acts[k], op)
+                if stopped.any():
+                    O.reset(planes, envs, seed=43, mask=stopped, params=op)
+                    ro[stopped], do[stopped] = 0.0, 0
+                    resets += int(stopped.sum())
+                outs.append((ro, do))
+            d_act = None if acts is None else torch.from_numpy(acts).to(dev)
+            d_r = torch.full((n, B), -7.0, dtype=torch.float64, device=dev)
+            d_d = torch.full((n, B), 9, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()                     # (torch's stream: the inputs exist; the context's streams run on)
+            env.step_device(d_act, n, d_r, d_d, update_mask=(1 << n) - 1)
+            issued.append((n, outs, d_r, d_d, d_act))
+        gp, ge = env.download()                          # joins the context's streams
+        np.testing.assert_array_equal(gp, planes, err_msg=f"group {g}: planes")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"group {g}: envs")
+        for i, (n, outs, d_r, d_d, _) in enumerate(issued):
+            r, d = d_r.cpu().numpy(), d_d.cpu().numpy()
+            for k in range(n):
+                np.testing.assert_array_equal(r[k], outs[k][0], err_msg=f"group {g} call {i} (n={n}) step {k}: reward")
+                np.testing.assert_array_equal(d[k], outs[k][1], err_msg=f"group {g} call {i} (n={n}) step {k}: done")
+    assert resets > B // 4
     env.close()
 
 

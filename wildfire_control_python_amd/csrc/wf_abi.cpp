@@ -34,6 +34,9 @@ struct wf_ctx {
     hipStream_t side[WF_MAX_SIDE] = {};
     hipEvent_t ev_side[WF_MAX_SIDE] = {}, ev_fork = nullptr;
     int n_parts = 2;                  // launches per step (WF_SPLIT overrides, 1 = never split)
+    int n_side = 0;                   // side streams that exist (own streams: WF_MAX_SIDE; a call may use fewer than there are)
+    int last_parts = 0;               // parts of the last split call: another number of parts maps environments to other streams
+    int side_used = 0;                // side streams with work since the last join
     WfKnobs knobs = {};               // WF_* experiment switches, read once (wf_create / wf_reload_env)
     bool sync_call = false;           // inside a synchronous host-buffer call: one launch, no fork / join (see wf_step_obs)
     bool side_pending = false;        // work enqueued on `side` that `stream` has not waited for yet
@@ -257,11 +260,12 @@ WfArgs base_args(const wf_ctx *c)
 int join_side(wf_ctx *c)
 {
     if (c->side_pending) {         // recorded lazily: an event per step would serialise the side queues
-        for (int i = 0; i < c->n_parts - 1; ++i) {
+        for (int i = 0; i < c->side_used; ++i) {
             HIP_TRY(c, hipEventRecord(c->ev_side[i], c->side[i]));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[i], 0));
         }
         c->side_pending = false;
+        c->side_used = 0;
     }
     c->main_touched = true;
     return WF_OK;
@@ -272,6 +276,22 @@ int join_side(wf_ctx *c)
         int _rc = join_side(c);              \
         if (_rc != WF_OK) return _rc;        \
     } while (0)
+
+// Start of a call that goes out as `parts` launches on the context's streams (main + parts - 1 side streams).  The sides
+// must see earlier reset / upload / get_state work of `stream`; and a call with ANOTHER number of parts than the last one
+// cuts the batch elsewhere, so its parts depend on what other streams did before: everything joins `stream` first.
+int begin_split(wf_ctx *c, int parts)
+{
+    if (c->last_parts != 0 && c->last_parts != parts) JOIN(c);      // (sets main_touched: the fork below follows)
+    if (c->main_touched) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int i = 0; i < parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+        c->main_touched = false;
+    }
+    c->last_parts = parts;
+    if (c->side_used < parts - 1) c->side_used = parts - 1;
+    return WF_OK;
+}
 
 // A single step of a large batch on the context's OWN streams goes out as n_parts concurrent launches.
 bool splits(const wf_ctx *c, int n_steps)
@@ -313,10 +333,22 @@ int push_cold(wf_ctx *c)
 }
 
 // environments per part of a split launch
-int split_per(const wf_ctx *c)
+int split_per(const wf_ctx *c, int parts = 0)
 {
+    if (parts <= 0) parts = c->n_parts;
     const int al = wf_split_align(c->W, c->H, c->knobs);
-    return ((c->batch + c->n_parts - 1) / c->n_parts + al - 1) / al * al;
+    return ((c->batch + parts - 1) / parts + al - 1) / al * al;
+}
+
+// Parts of an n-step call served by wf_step_ticks (0: one launch).  Measured at 16 ticks per call, no actions
+// (profiles/r04_ticks_split.txt; us per call as 1 / 2 / 4 launches): 2 048 x 10x10 12.1 / 10.7 / 12.0, 4 096 17.4 / 13.7 / 13.0,
+// 8 192 28.3 / 22.0 / 21.1, 16 384 51.7 / 41.5 / 41.7; below 2 048 environments one launch is fastest.
+int ticks_parts(const wf_ctx *c)
+{
+    if (c->knobs.ticks_split <= 0 || c->batch < c->knobs.ticks_split || !c->own_stream || c->n_parts <= 1 || c->knobs.no_split) return 0;
+    if (c->knobs.n_parts > 0 && c->knobs.split_explicit) return c->n_parts;                 // WF_SPLIT given: that many
+    const int most = c->n_side + 1;
+    return c->batch >= 2 * c->knobs.ticks_split ? (most < 4 ? most : 4) : 2;
 }
 
 // Is an n_steps call of this (split) context served by the rows kernel's own step loop?  Probed with the FIRST part's
@@ -427,7 +459,12 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
         a.done = d_done ? d_done + soff : nullptr;
         a.n_steps = each ? 1 : n_steps;
         a.update_mask = each ? (update_mask >> st) & 1ull : update_mask;
-        const bool split = !ticks && splits(c, in_kernel ? 1 : a.n_steps);
+        // An n-step call served by wf_step_ticks goes out as several launches on the context's streams (round 4): one part's
+        // launch ramp, loads and tail run under the other parts' ticks, and the parts' waves are out of step with each other.
+        // 4 096 x 10x10 x 16 ticks: 13.0-13.7 against 17.3 us per call (ticks_parts above).
+        const bool ticks_call = n_steps > 1 && calm && !in_kernel && !each;
+        const int tparts = ticks_call && !c->sync_call ? ticks_parts(c) : 0;
+        const bool split = tparts > 1 || (!ticks && splits(c, in_kernel ? 1 : a.n_steps));
         if (!split) {
             JOIN(c);
             HIP_TRY(c, wf_launch_step(c->fam, a, kn, c->stream, c->num_cus));
@@ -435,14 +472,14 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
         }
         // independent parts of the batch on separate streams (inputs must be complete when this is
         // called: the context's own streams are not ordered with the caller's streams)
-        if (c->main_touched) {         // the sides must see earlier reset / upload / get_state work of `stream`
-            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-            for (int i = 0; i < c->n_parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-            c->main_touched = false;
+        const int parts = tparts > 1 ? tparts : c->n_parts;
+        {
+            const int rc = begin_split(c, parts);
+            if (rc != WF_OK) return rc;
         }
-        const int per = split_per(c);
+        const int per = split_per(c, parts);
         if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);   // as for the whole batch
-        for (int i = 0; i < c->n_parts; ++i) {
+        for (int i = 0; i < parts; ++i) {
             const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
             if (lo >= hi) break;
             WfArgs ai = a;
@@ -644,7 +681,9 @@ int wf_create(wf_ctx **out, int device, int batch, int H, int W, const wf_params
         const int want = c->knobs.n_parts > 0 ? c->knobs.n_parts : fam == WF_FAM_WAVE ? 2 : 3;
         c->n_parts = want > WF_MAX_SIDE + 1 ? WF_MAX_SIDE + 1 : want;
         c->knobs.n_parts = c->n_parts;
-        for (int i = 0; i < c->n_parts - 1 && e == hipSuccess; ++i) {
+        // (all WF_MAX_SIDE side streams exist whatever n_parts says: n-step calls of wf_step_ticks use up to four parts)
+        c->n_side = c->n_parts > 1 ? WF_MAX_SIDE : 0;
+        for (int i = 0; i < c->n_side && e == hipSuccess; ++i) {
             if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) break;
             e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming);
         }
@@ -869,11 +908,8 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
     const int parts = split ? c->n_parts : 1;
     const int per = (c->batch + parts - 1) / parts;
     if (split) {
-        if (c->main_touched) {
-            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-            for (int i = 0; i < parts - 1; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-            c->main_touched = false;
-        }
+        const int rc = begin_split(c, parts);
+        if (rc != WF_OK) return rc;
     } else {
         JOIN(c);
     }
@@ -1149,9 +1185,13 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
     const int per_step = splits(c, 1) ? c->n_parts : 1;
     if (n_steps == 1) return per_step;
     if (c->p.wind_mode != WF_WIND_CALM) return per_step * n_steps;                      // wind: single-step launches only
-    if (!splits(c, 1)) return 1;                                                        // one (fused) launch
+    const int tp = ticks_parts(c) > 1 ? ticks_parts(c) : 1;                             // wf_step_ticks: one launch, or a few parts
+    if (!splits(c, 1)) {
+        const bool in_rows = (c->knobs.multi_small || !c->knobs.no_resident) && multi_rows_whole(c, n_steps);
+        return in_rows ? 1 : tp;
+    }
     const bool rows_loop = multi_rows_call(c, n_steps);
-    if (ticks_serves_split(c, true, rows_loop)) return 1;                               // (a call with actions, as above)
+    if (ticks_serves_split(c, true, rows_loop)) return tp;                              // (a call with actions, as above)
     return rows_loop ? c->n_parts : c->n_parts * n_steps;
 }
 

@@ -75,6 +75,8 @@ struct WfKnobs {
     int cells_legacy; // WF_CELLS_LEGACY: generic family as the five-launch thread-per-cell sequence for every batch
     int multi_small; // WF_MULTI_SMALL: n-step calls of batches that are not split also use the rows kernel's step loop
     int host_stage_mode; // WF_HOST_STAGE_MODE: 1 actions through a device mirror, 2 reward / done, 3 both (default of the experiment)
+    int ticks_split;     // WF_TICKS_SPLIT (default 2048): smallest batch whose n-step wf_step_ticks calls go out as several launches on the context's streams (0: never)
+    int split_explicit;  // WF_SPLIT was given: every split call uses exactly that many parts
     int sweep_alt;       // WF_SWEEP_ALT (default 1): the tiled step kernels walk the batch forwards and backwards in turn, so that a step
                          // starts on the bytes the step before touched last (still in the Infinity Cache); 0 = always forwards
     int fused_legacy;    // WF_FUSED_LEGACY: n-step calls of one environment per wave on wf_step_wave (unpacked cells, agent logic on the vector unit) instead of wf_step_ticks

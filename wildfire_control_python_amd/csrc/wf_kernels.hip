@@ -646,6 +646,8 @@ void wf_read_knobs(WfKnobs *k)
     k->fused_legacy = set("WF_FUSED_LEGACY");
     k->sweep_alt = num("WF_SWEEP_ALT", 1);     // (1 024 x 256x256: 82 against 86 us per step; tools/sweep_alt.sh)
     k->host_stage_mode = num("WF_HOST_STAGE_MODE", 0);
+    k->ticks_split = num("WF_TICKS_SPLIT", 2048);
+    k->split_explicit = set("WF_SPLIT") ? 1 : 0;
     k->multi_rows = 0;
 }
 
