@@ -467,7 +467,9 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
         const bool split = tparts > 1 || (!ticks && splits(c, in_kernel ? 1 : a.n_steps));
         if (!split) {
             JOIN(c);
-            HIP_TRY(c, wf_launch_step(c->fam, a, kn, c->stream, c->num_cus));
+            WfKnobs k1 = kn;
+            k1.whole_batch = 1;
+            HIP_TRY(c, wf_launch_step(c->fam, a, k1, c->stream, c->num_cus));
             continue;
         }
         // independent parts of the batch on separate streams (inputs must be complete when this is

@@ -28,7 +28,8 @@ struct WfCold {
     double wind_c[4][16][4];
 };
 
-enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8, WF_HOT_WIND = 16 };
+enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8, WF_HOT_WIND = 16,
+       WF_HOT_PROGRESS_PRIO = 32 };   // (per launch, set by the launcher: see set_progress_prio in wf_wave_rows.h)
 // The two options that are off in the reference's default configuration (constants.py:44,46) live in separate
 // instantiations of the step kernels (template parameter RARE), so that they cost the default path neither
 // registers nor instructions.
@@ -84,6 +85,8 @@ struct WfKnobs {
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
+    int no_prio;     // WF_NO_PRIO: never set WF_HOT_PROGRESS_PRIO
+    int whole_batch; // per call (not an environment switch): this launch steps the whole batch alone (no part launches beside it)
     int multi_rows;  // per call (not an environment switch): n_steps > 1 is served by the rows kernel's step loop
 };
 void wf_read_knobs(WfKnobs *k);

@@ -567,6 +567,9 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         WfArgs g = a;
         g.group = p.G;
         const int waves = (a.batch + p.G - 1) / p.G;
+        // a launch that steps the whole batch alone with one generation of waves (at most the chip's 32 per CU, at least half
+        // of them): its waves lower their issue priority as they get ahead (set_progress_prio; WF_NO_PRIO=1 switches it off)
+        if (k.whole_batch && !k.no_prio && a.n_steps <= 1 && waves <= num_cus * 32 && waves >= num_cus * 12) g.hot_flags |= WF_HOT_PROGRESS_PRIO;
         const dim3 grid_private((waves + 3) / 4), grid_shared((a.batch + 63) / 64), block_shared(64 * (64 / p.G));
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
@@ -649,6 +652,8 @@ void wf_read_knobs(WfKnobs *k)
     k->ticks_split = num("WF_TICKS_SPLIT", 2048);
     k->split_explicit = set("WF_SPLIT") ? 1 : 0;
     k->multi_rows = 0;
+    k->whole_batch = 0;
+    k->no_prio = set("WF_NO_PRIO");
 }
 
 // environments per wave iteration of the shape's rows-layout kernel (0: the shape has none, or WF_NO_ROWS)

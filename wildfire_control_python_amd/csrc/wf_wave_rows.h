@@ -239,15 +239,14 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
 // for the same pipe, the staircase had them in different phases.  23.7 vs 25.3 us per step as one launch, but 22.3 vs
 // 20.3 with the two half-batch launches, 34.9 vs 30.8 at 125 000 envs, 66.7 vs 60.3 at 262 144: off by default.
 template <int LEVEL>
-__device__ __forceinline__ void set_progress_prio(uint32_t done, uint32_t total)
+__device__ __forceinline__ void set_progress_prio(bool on, uint32_t done, uint32_t total)
 {
-#if WF_PROGRESS_PRIO
+    if (!on) return;
     const uint32_t q = (done * 4u) / total;                 // wave-uniform
     if (q == 0u) __builtin_amdgcn_s_setprio(3);
     else if (q == 1u) __builtin_amdgcn_s_setprio(2);
     else if (q == 2u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // Waves per workgroup of the private (not workgroup-shared) variant.  The dispatcher hands out workgroups, so fewer,
@@ -315,9 +314,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         planes_wave = mirror - (size_t)e0 * CELLS;
     }
-#if WF_PROGRESS_PRIO
-    if constexpr (!SHARED && !MULTI) __builtin_amdgcn_s_setprio(3);
-#endif
+    // (round 4: per launch - WF_HOT_PROGRESS_PRIO is set for a launch that steps the whole batch alone with one generation of
+    // waves: 65 536 envs 24.0 -> 22.6 us, 32 768 16.3 -> 15.6; the part launches of a split step run without it)
+    const bool prio_on = !SHARED && !MULTI && (WF_PROGRESS_PRIO || (a0.hot_flags & WF_HOT_PROGRESS_PRIO) != 0);
+    if (prio_on) __builtin_amdgcn_s_setprio(3);
 #ifdef WF_WAVE_TIMING   // measurement build (tools/wave_timeline.py): 100 MHz wall clock at the phase borders of every wave
     const u64 wt0 = wall_clock64();
     u64 wtA = 0, wtB = 0;
@@ -406,7 +406,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         // board of the iteration's group (context-level group index), advanced with the loop
         u64 *board = a.reach_rows + (size_t)((a.env_base + e0) / (uint32_t)EPW) * CPL;
         for (uint32_t kb = 0; kb < ng; kb += (uint32_t)EPW, off += (uint32_t)EPW * ENV_BYTES, board += CPL) {
-            if constexpr (!SHARED && !MULTI) set_progress_prio<0>(kb, G);
+            if constexpr (!SHARED && !MULTI) set_progress_prio<0>(prio_on, kb, G);
             if (kb + hh < ng) {
                 const uint32_t eoff = off + hh * ENV_BYTES;
                 uint32_t c[CPL];
