@@ -2142,6 +2142,62 @@ def test_device_calls_with_changing_part_counts(wf, monkeypatch, W, H, B, split)
     env.close()
 
 
+def test_alternating_sweeps_of_the_rows_kernel_change_nothing(wf, monkeypatch):
+    """A state past the Infinity Cache (300 000 x 14x14 = 235 MB): single steps walk the batch forwards and backwards in
+    turn (round 4; a launch argument of the rows kernel).  The order in which a launch visits its environments must not
+    show: the same steps with WF_SWEEP_ALT=0, and the oracle on the first and last 2 048 environments."""
+    B, S, T = 300000, 14, 7
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 5, size=(T, B)).astype(np.int8)
+    out = []
+    for alt in ("1", "0"):
+        monkeypatch.setenv("WF_SWEEP_ALT", alt)
+        env = wf.BatchedForestFire(B, size=S, seed=77, auto_reset=True, containment=True, fuel_range=(2, 5))
+        assert env.step_kernel.startswith("wf_step_rows") and env.step_launches == 2
+        env.reset(seed=77)
+        import torch
+        dev = torch.device("cuda", 0)
+        d_act = torch.from_numpy(acts).to(dev)
+        d_r = torch.empty((T, B), dtype=torch.float64, device=dev)
+        d_d = torch.empty((T, B), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        rs = []
+        for t in range(T):
+            if t == 3:                                   # a synchronous host-buffer step in between: ONE launch over the whole batch
+                r, d = env.step_many(acts[t:t + 1])
+                rs.append((r[0].copy(), d[0].astype(np.uint8)))
+            else:                                        # device API: two part launches on the context's streams
+                env.step_device(d_act[t], 1, d_r[t:t + 1], d_d[t:t + 1], update_mask=1)
+                rs.append(None)
+        planes_envs = env.download()
+        hr, hd = d_r.cpu().numpy(), d_d.cpu().numpy()
+        rs = [x if x is not None else (hr[t], hd[t]) for t, x in enumerate(rs)]
+        out.append((planes_envs, rs))
+        env.close()
+        del d_act, d_r, d_d
+    monkeypatch.delenv("WF_SWEEP_ALT", raising=False)
+    (pa, ea), ra = out[0]
+    (pb, eb), rb = out[1]
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(_envs(ea), _envs(eb))
+    for t in range(T):
+        np.testing.assert_array_equal(ra[t][0], rb[t][0], err_msg=f"reward step {t}")
+        np.testing.assert_array_equal(ra[t][1], rb[t][1], err_msg=f"done step {t}")
+    # the oracle on both ends of the batch (streams keyed by the environment's index in the context)
+    op = O.default_params(containment=1, fuel_lo=2, fuel_hi=5)
+    for lo in (0, B - 2048):
+        planes, envs = O.new_state(2048, S, S)
+        O.reset(planes, envs, seed=77, env_id0=lo, params=op)
+        for t in range(T):
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, acts[t, lo:lo + 2048], op)
+            if stopped.any():
+                O.reset(planes, envs, seed=77, mask=stopped, env_id0=lo, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+            np.testing.assert_array_equal(ra[t][0][lo:lo + 2048], ro, err_msg=f"oracle reward step {t} envs {lo}..")
+        np.testing.assert_array_equal(pa[lo:lo + 2048], planes, err_msg=f"oracle planes envs {lo}..")
+
+
 # ------------------------------------------------ rows layout with an odd number of environments per iteration
 @pytest.mark.parametrize("W,H,group,B", [(8, 8, "7", 4096 + 37), (8, 8, "14", 4096 + 37), (16, 8, "6", 4096 + 37), (8, 16, "3", 4096 + 37),
                                          (8, 8, None, 40000), (8, 16, None, 36000), (16, 8, "12", 9000 + 11)])

@@ -459,6 +459,10 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
         a.done = d_done ? d_done + soff : nullptr;
         a.n_steps = each ? 1 : n_steps;
         a.update_mask = each ? (update_mask >> st) & 1ull : update_mask;
+        // A state past the 256 MB Infinity Cache: single steps walk the batch forwards and backwards in turn, so that a step
+        // starts on the bytes the step before touched last (the rows kernel only; 1 M x 14x14: 335 -> 320 us per step in
+        // round 3's experiment, which paid for it at every size; now a launch argument set for these sizes only)
+        if (c->knobs.sweep_alt && a.n_steps == 1 && cells * (size_t)c->batch * 4 > ((size_t)224 << 20)) a.sweep_rev = (int32_t)(c->sweeps++ & 1u);
         // An n-step call served by wf_step_ticks goes out as several launches on the context's streams (round 4): one part's
         // launch ramp, loads and tail run under the other parts' ticks, and the parts' waves are out of step with each other.
         // 4 096 x 10x10 x 16 ticks: 13.0-13.7 against 17.3 us per call (ticks_parts above).

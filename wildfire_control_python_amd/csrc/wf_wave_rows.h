@@ -292,7 +292,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         e0 = A0 + gi0;
         ng = gi0 < na ? min(G, na - gi0) : 0u;
     } else {
-        e0 = rfl(blockIdx.x * (uint32_t)WF_ROWS_WPB + wv) * G;
+        // (a0.sweep_rev: this launch walks its environments from the far end - states past the Infinity Cache, see wave_step_issue)
+        const uint32_t bid = a0.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+        e0 = rfl(bid * (uint32_t)WF_ROWS_WPB + wv) * G;
         if (e0 >= batch) return;
         ng = min(G, batch - e0);
         A0 = e0;
@@ -500,6 +502,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                         c[j] = addc(c[j], add, IGN);                                   // grass -> fire: +1 through the carry-in
                         chg |= add;                                                    // (an ignition always comes with heat)
                         IGNANY |= IGN;
+#ifdef WF_EXP_EXTRA_SALU     // timing experiment: WF_EXP_EXTRA_SALU extra scalar instructions per cell slot (results unused)
+#pragma unroll
+                        for (int x = 0; x < WF_EXP_EXTRA_SALU; ++x) { u64 dm; asm volatile("s_and_b64 %0, %1, %1" : "=s"(dm) : "s"(IGNANY) : "scc"); }
+#endif
 #ifdef WF_EXP_EXTRA_VALU     // timing experiment: WF_EXP_EXTRA_VALU extra vector compares per cell slot (results unused, state unchanged)
 #pragma unroll
                         for (int x = 0; x < WF_EXP_EXTRA_VALU; ++x) { u64 dm; asm volatile("v_cmp_eq_u32_e64 %0, %1, %1" : "=s"(dm) : "v"(c[j])); }
