@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/prof_{tag}"
 
 RUNS = [  # (directory, what was run)
@@ -60,7 +60,10 @@ for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; 
                         ("c4", "wf_step_tiled", "1 024 x 256x256 (268 MB; WF_NO_SPLIT=1, ticks 60..120 after the reset, --min-ms 0)"),
                         ("hbm", "wf_step_rows", "1 048 576 x 14x14 (822 MB; WF_NO_SPLIT=1, steps 60..100, --min-ms 0)"),
                         ("c5", "wf_step_rows", "125 000 x 14x14 (98 MB, one shard of configs[4]; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
-                        ("c2", "wf_step_ticks", "4 096 x 10x10, no-op, 16 ticks per launch (1.6 MB; the c2 leg of a default bench run; per LAUNCH = per 16 ticks)")):
+                        ("c2", "wf_step_ticks", "4 096 x 10x10, no-op, 16 ticks per call (1.6 MB; the c2 leg of a bench run under WF_NO_SPLIT=1: ONE launch per call; "
+                                               "un-profiled a call is four part launches on the context's streams)"),
+                        ("wind", "wf_step_group", "65 536 x 14x14, wind 'random' (51 MB of planes + 51 MB of heat counts; the c3_wind leg of a bench run under WF_NO_SPLIT=1: one launch per step)"),
+                        ("mid", "wf_step_tiled", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch sequence per step; wf_step_tiled only)")):
     lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
     for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
         if not os.path.isdir(d):
@@ -105,10 +108,13 @@ t["other_sizes"]["c5_shard"] = traffic("c5", "wf_step_rows<14,14,2,false>", 1250
 t["other_sizes"]["c2"] = traffic("c2", "wf_step_ticks<10,10,false>", 4096 * 100, "4096 x 10x10, no-op, 16 ticks per launch (BASELINE configs[1]); the grid "
                                  "stays in registers between the ticks, so a launch moves the state once: compare with state_bytes, not with the 16 ticks' algorithmic bytes")
 t["other_sizes"]["c2"]["algorithmic_bytes_per_launch"] = 4096 * 100 * 8 * 16
+t["other_sizes"]["c3_wind"] = traffic("wind", "wf_step_group<14,14,wind>", 65536 * 196, "65536 x 14x14, wind 'random' (planes + per-direction heat counts), bench inputs")
+t["other_sizes"]["mid_64"] = traffic("mid", "wf_step_tiled", 4096 * 4096, "4096 x 64x64, bench inputs (67 MB; wf_step_tiled only: the prologue's traffic is not in it)")
 # what bench.py looks up, per leg of its JSON line; every entry names the PMC pass it came from
 t["kernel_source_sha256"] = open(f"{src}/kernel_source_sha256.txt").read().strip()
 t["legs"] = {}
-for leg, key, cfg in (("c3", None, "c3"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5"), ("c2", "c2", "c2")):
+for leg, key, cfg in (("c3", None, "c3"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5"), ("c2", "c2", "c2"),
+                      ("c3_wind", "c3_wind", "wind"), ("mid_64", "mid_64", "mid")):
     e = dict(t if key is None else t["other_sizes"][key])
     for k in ("other_sizes", "legs", "note", "round", "kernel_source_sha256"):
         e.pop(k, None)

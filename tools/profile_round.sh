@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage (GPU box): bash tools/profile_round.sh r02   -> gpurun_out/prof_<tag>/...
+# usage (GPU box): bash tools/profile_round.sh r04   -> gpurun_out/prof_<tag>/...
 # rocprofv3 kernel-trace stats and HBM traffic counters (separate --pmc passes: FETCH_SIZE and WRITE_SIZE do not
 # fit one pass; MI355X_MICROARCH.md) for
 #   c3     65 536 x 14x14 (headline; default two-launch step, and one launch per step)
 #   c4     1 024 x 256x256, 1 % pre-ignited, no-op (wf_step_tiled + wf_big_*; 268 MB of state: past the 256 MB Infinity Cache)
 #   hbm    1 048 576 x 14x14 (wf_step_rows on 822 MB of state: true HBM streaming)
 #   c2     4 096 x 10x10, no-op, 16 ticks per call (wf_step_ticks; the leg of the default bench line)
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 B="python3 bench.py --no-extras --no-cpu-baseline"
@@ -14,6 +14,8 @@ C4="--size 256 --batch 1024 --noop --ignite-ppm 10000 --steps 200 --warmup 20"
 HB="--batch 1048576 --steps 120 --warmup 20"
 C5="--batch 125000 --steps 400 --warmup 40"
 C2="python3 bench.py --no-cpu-baseline --legs c2 --steps 100 --warmup 10 --fused 0"    # (the headline loop runs too; the wf_step_ticks rows are the leg's)
+WIND="python3 bench.py --no-cpu-baseline --legs c3_wind --steps 100 --warmup 10 --fused 0"   # (wf_step_group<..,WIND> rows: the leg)
+MID="python3 bench.py --no-cpu-baseline --legs mid_64 --steps 100 --warmup 10 --fused 0"     # (wf_step_tiled / wf_tiled_prologue rows: the leg)
 python3 -c "import bench; print(bench.kernel_source_sha256())" > $out/kernel_source_sha256.txt
 PM="--steps 40 --warmup 400"
 # ---- kernel-trace stats
@@ -36,10 +38,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_hbm_$c -- $B $HB --steps 40 --warmup 60 --min-ms 0 > $out/pmc_hbm_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_c5_$c -- $B --batch 125000 $PM > $out/pmc_c5_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_c2_$c -- $C2 > $out/pmc_c2_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_wind_$c -- $WIND > $out/pmc_wind_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_mid_$c -- $MID > $out/pmc_mid_$c.log 2>&1
 done
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_c3_l2 -- $B $PM > $out/pmc_c3_l2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_c3_insts -- $B $PM > $out/pmc_c3_insts.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_c2_insts -- $C2 > $out/pmc_c2_insts.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_c3_active -- $B $PM > $out/pmc_c3_active.log 2>&1
 unset WF_NO_SPLIT
 python3 tools/c4_write_amp.py > $out/c4_write_amp.json 2> $out/c4_write_amp.err
 # ---- the same bench un-profiled, for the agreement check
