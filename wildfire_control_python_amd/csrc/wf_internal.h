@@ -28,8 +28,7 @@ struct WfCold {
     double wind_c[4][16][4];
 };
 
-enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8, WF_HOT_WIND = 16,
-       WF_HOT_PROGRESS_PRIO = 32 };   // (per launch, set by the launcher: see set_progress_prio in wf_wave_rows.h)
+enum { WF_HOT_CONTAINMENT = 1, WF_HOT_AUTO_RESET = 2, WF_HOT_DIG_TOGGLE = 4, WF_HOT_RIVERS = 8, WF_HOT_WIND = 16 };
 // The two options that are off in the reference's default configuration (constants.py:44,46) live in separate
 // instantiations of the step kernels (template parameter RARE), so that they cost the default path neither
 // registers nor instructions.

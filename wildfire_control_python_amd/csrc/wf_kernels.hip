@@ -569,7 +569,7 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
         const int waves = (a.batch + p.G - 1) / p.G;
         // a launch that steps the whole batch alone with one generation of waves (at most the chip's 32 per CU, at least half
         // of them): its waves lower their issue priority as they get ahead (set_progress_prio; WF_NO_PRIO=1 switches it off)
-        if (k.whole_batch && !k.no_prio && a.n_steps <= 1 && waves <= num_cus * 32 && waves >= num_cus * 12) g.hot_flags |= WF_HOT_PROGRESS_PRIO;
+        const bool prio = k.whole_batch && !k.no_prio && a.n_steps <= 1 && waves <= num_cus * 32 && waves >= num_cus * 12;
         const dim3 grid_private((waves + 3) / 4), grid_shared((a.batch + 63) / 64), block_shared(64 * (64 / p.G));
         if constexpr (HasRows<W, H>::value) {
             constexpr int S = HasRows<W, H>::S;
@@ -581,7 +581,10 @@ hipError_t launch_wave(bool reset, const WfArgs &a, const WfKnobs &k, hipStream_
             if (p.kind == STEP_ROWS && a.n_steps > 1 && rare && res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true, true>), grid_rows, block_rows, mirror_bytes, s, g);
             if (p.kind == STEP_ROWS && a.n_steps > 1 && !rare && !res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, false>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS && a.n_steps > 1 && rare && !res) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, true, true>), grid_rows, block_rows, 0, s, g);
-            if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false>), grid_rows, block_rows, 0, s, g);
+            const bool rev = a.sweep_rev != 0 && !rare && !prio;
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare && !prio && !rev) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false>), grid_rows, block_rows, 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && rev) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false, false, false, true>), grid_rows, block_rows, 0, s, g);
+            if (p.kind == STEP_ROWS && a.n_steps <= 1 && !rare && prio) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, false, false, true>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS && a.n_steps <= 1 && rare) hipLaunchKernelGGL((wf_step_rows<W, H, S, false, false, true>), grid_rows, block_rows, 0, s, g);
             if (p.kind == STEP_ROWS_SHARED) {
                 // WF_SHARED=N with N in {2,4,8}: N waves share the agent phases (N*G <= 64 environments per workgroup)

@@ -238,10 +238,10 @@ __device__ __forceinline__ void reset_rows(const WfCold *cold_g, u64 seed, uint3
 // a SIMD then end within 3 us of each other - but the SIMD is not done earlier: eight waves in the SAME phase compete
 // for the same pipe, the staircase had them in different phases.  23.7 vs 25.3 us per step as one launch, but 22.3 vs
 // 20.3 with the two half-batch launches, 34.9 vs 30.8 at 125 000 envs, 66.7 vs 60.3 at 262 144: off by default.
-template <int LEVEL>
-__device__ __forceinline__ void set_progress_prio(bool on, uint32_t done, uint32_t total)
+template <bool ON>
+__device__ __forceinline__ void set_progress_prio(uint32_t done, uint32_t total)
 {
-    if (!on) return;
+    if constexpr (!ON) return;
     const uint32_t q = (done * 4u) / total;                 // wave-uniform
     if (q == 0u) __builtin_amdgcn_s_setprio(3);
     else if (q == 1u) __builtin_amdgcn_s_setprio(2);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void set_progress_prio(bool on, uint32_t done, uint32
 #ifndef WF_RES_MAXG
 #define WF_RES_MAXG 8        // environments per wave of the resident loop (LDS mirror: WF_RES_MAXG x W x H x 4 bytes per wave)
 #endif
-template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE, bool RES = false>
+template <int W, int H, int S, bool SHARED, bool MULTI, bool RARE, bool RES = false, bool PRIO = false, bool REV = false>
 // Waves per SIMD: minimum = maximum = 8.  (A minimum of 7 gives the register allocator 94 scalar registers instead of
 // 80 and removes a third of the scalar spills to VGPR lanes, and the compiler still reports 8 waves per SIMD - but a
 // wave's 94 SGPRs are allocated as 112, 800 / 112 = 7: tools/wave_timeline.py showed exactly one workgroup in eight
@@ -292,8 +292,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         e0 = A0 + gi0;
         ng = gi0 < na ? min(G, na - gi0) : 0u;
     } else {
-        // (a0.sweep_rev: this launch walks its environments from the far end - states past the Infinity Cache, see wave_step_issue)
-        const uint32_t bid = a0.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+        // (REV: this launch walks its environments from the far end - states past the Infinity Cache, see wave_step_issue; an
+        // instantiation of its own: as a launch argument it cost the headline kernel three more spilled scalar registers, 1.5 %)
+        const uint32_t bid = REV ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
         e0 = rfl(bid * (uint32_t)WF_ROWS_WPB + wv) * G;
         if (e0 >= batch) return;
         ng = min(G, batch - e0);
@@ -316,10 +317,12 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         planes_wave = mirror - (size_t)e0 * CELLS;
     }
-    // (round 4: per launch - WF_HOT_PROGRESS_PRIO is set for a launch that steps the whole batch alone with one generation of
+    // (round 4: per launch - the PRIO instantiation serves a launch that steps the whole batch alone with one generation of
     // waves: 65 536 envs 24.0 -> 22.6 us, 32 768 16.3 -> 15.6; the part launches of a split step run without it)
-    const bool prio_on = !SHARED && !MULTI && (WF_PROGRESS_PRIO || (a0.hot_flags & WF_HOT_PROGRESS_PRIO) != 0);
-    if (prio_on) __builtin_amdgcn_s_setprio(3);
+    // (an instantiation of its own, PRIO: as a run-time flag it cost the part launches of a split step 1.5 % - one more live
+    // wave-uniform value in a kernel that already spills scalar registers)
+    constexpr bool prio_on = !SHARED && !MULTI && (WF_PROGRESS_PRIO || PRIO);
+    if constexpr (prio_on) __builtin_amdgcn_s_setprio(3);
 #ifdef WF_WAVE_TIMING   // measurement build (tools/wave_timeline.py): 100 MHz wall clock at the phase borders of every wave
     const u64 wt0 = wall_clock64();
     u64 wtA = 0, wtB = 0;
@@ -408,7 +411,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
         // board of the iteration's group (context-level group index), advanced with the loop
         u64 *board = a.reach_rows + (size_t)((a.env_base + e0) / (uint32_t)EPW) * CPL;
         for (uint32_t kb = 0; kb < ng; kb += (uint32_t)EPW, off += (uint32_t)EPW * ENV_BYTES, board += CPL) {
-            if constexpr (!SHARED && !MULTI) set_progress_prio<0>(prio_on, kb, G);
+            set_progress_prio<prio_on>(kb, G);
             if (kb + hh < ng) {
                 const uint32_t eoff = off + hh * ENV_BYTES;
                 uint32_t c[CPL];
