@@ -13,6 +13,9 @@
 // configs[1] (4 096 x 10x10, 16 ticks per call: four waves per SIMD) is bound by instruction issue - 72 vector + 84 scalar
 // instructions per tick in the no-action loop, and the scalar unit issues one instruction per cycle for the four SIMDs
 // of a CU, i.e. a SIMD gets a scalar slot as often as a vector slot: scalar instructions are not free.
+// Round 4: a call of 2 048 environments or more goes out as two or four launches of this kernel on the context's streams
+// (wf_abi.cpp: ticks_parts) - 4 096 x 10x10 x 16 ticks 17.3 -> 13.1 us per call; the vector forms used here (compares, mask read-backs,
+// carry-in adds) issue at 4.25 cycles per wave64 instruction, the rate of the scalar unit (profiles/r04_issue_rates_*.txt).
 
 // type byte of cell q (wave-uniform q) of the packed grid c
 __device__ __forceinline__ uint32_t cell_type_at(const uint32_t (&c)[4], uint32_t q)
