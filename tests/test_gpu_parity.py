@@ -473,6 +473,9 @@ KERNEL_VARIANTS = {
     "rows-g22-ragged": {"WF_GROUP": "22", "WF_ROWS": "1"},
     "rows-shared-g8": {"WF_GROUP": "8", "WF_SHARED": "1"},
     "rows-shared-g16": {"WF_GROUP": "16", "WF_SHARED": "1"},
+    "rows-shared4-g4": {"WF_GROUP": "4", "WF_SHARED": "4"},          # (round 4: the shape of a one-generation step on 14x14)
+    "rows-shared2-g4": {"WF_GROUP": "4", "WF_SHARED": "2"},
+    "rows-shared8-g2": {"WF_GROUP": "2", "WF_SHARED": "8"},
 }
 
 
@@ -1363,31 +1366,62 @@ def test_fire_in_direction_on_a_constructed_state(wf):
 
 
 # ---------------------------------------------------------------- consumers of the path
-def test_full_size_every_environment_matches_oracle(wf):
-    """BASELINE config 3 exactly as bench.py runs it (65 536 x 14x14, two half-batch launches of the rows
-    kernel per step, auto-reset, containment): every environment against the oracle, rewards and done flags
-    each step, the whole state at the end."""
+@pytest.mark.parametrize("onegen", [True, False])
+def test_full_size_every_environment_matches_oracle(wf, monkeypatch, onegen):
+    """BASELINE config 3 exactly as bench.py runs it: 65 536 x 14x14 through the asynchronous DEVICE API on the context's own
+    streams, auto-reset, containment.  Since round 4 a single step of this size goes out as THREE part launches of the rows
+    kernel with 4 environments per wave and the agent phases shared by a workgroup's 4 waves (onegen; WF_NO_ONEGEN=1: the
+    two half-batch launches of rounds 1-3).  Every environment against the oracle: rewards and done flags of every step, the
+    fused observation of some, a synchronous host-buffer step (one launch, issue priority by progress) in between, the whole
+    state at the end."""
+    import torch
+    for k in ("WF_GROUP", "WF_SHARED", "WF_SPLIT", "WF_NO_SPLIT", "WF_NO_ONEGEN", "WF_NO_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    if not onegen:
+        monkeypatch.setenv("WF_NO_ONEGEN", "1")
     B, S, T = 65536, 14, 40
     env = wf.BatchedForestFire(B, size=S, seed=5, auto_reset=True, containment=True, fuel_range=(3, 25), ignite_ppm=3000)
-    assert env.step_launches == 2 and env.step_kernel.startswith("wf_step_rows")
+    monkeypatch.delenv("WF_NO_ONEGEN", raising=False)
+    assert env.step_kernel == ("wf_step_rows<14,14,2,true>" if onegen else "wf_step_rows<14,14,2,false>"), env.step_kernel
+    assert env.step_launches == (3 if onegen else 2)
     env.reset(seed=5)
     op = O.default_params(containment=1, fuel_lo=3, fuel_hi=25, ignite_ppm=3000)
     planes, envs = O.new_state(B, S, S)
     O.reset(planes, envs, seed=5, params=op)
     rng = np.random.default_rng(5)
+    dev = torch.device("cuda", 0)
+    acts = rng.integers(0, 6, size=(T, B)).astype(np.int8)
+    d_act = torch.from_numpy(acts).to(dev)
+    d_r = torch.empty((T, B), dtype=torch.float64, device=dev)
+    d_d = torch.empty((T, B), dtype=torch.uint8, device=dev)
+    d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
+    torch.cuda.synchronize()
     resets = 0
+    exp = []
+    host = {}
     for t in range(T):
-        a = rng.integers(0, 6, size=B).astype(np.int8)
-        _, r, d, _ = env.step(a)
         stopped = (envs["flags"] & O.F_RUNNING) == 0
-        ro, do = O.step(planes, envs, a, op)
+        ro, do = O.step(planes, envs, acts[t], op)
         if stopped.any():
             O.reset(planes, envs, seed=5, mask=stopped, params=op)
             ro[stopped], do[stopped] = 0.0, 0
             resets += int(stopped.sum())
-        np.testing.assert_array_equal(r, ro, err_msg=f"reward t={t}")
-        np.testing.assert_array_equal(d, do.astype(bool), err_msg=f"done t={t}")
+        exp.append((ro, do))
+        if t == 17:                                  # synchronous host-buffer step: ONE launch over the whole batch
+            _, r, d, _ = env.step(acts[t])
+            host[t] = (r, d.astype(np.uint8))
+        elif t % 9 == 4:                             # the step kernel writes World.get_state() itself
+            env.step_device(d_act[t], 1, d_r[t:t + 1], d_d[t:t + 1], update_mask=1, d_obs=d_obs)
+            env.sync()
+            np.testing.assert_array_equal(d_obs.cpu().numpy(), O.get_state(planes), err_msg=f"obs t={t}")
+        else:
+            env.step_device(d_act[t], 1, d_r[t:t + 1], d_d[t:t + 1], update_mask=1)
     gp, ge = env.download()
+    hr, hd = d_r.cpu().numpy(), d_d.cpu().numpy()
+    for t in range(T):
+        r, d = host.get(t, (hr[t], hd[t]))
+        np.testing.assert_array_equal(r, exp[t][0], err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d, exp[t][1], err_msg=f"done t={t}")
     np.testing.assert_array_equal(gp, planes)
     np.testing.assert_array_equal(_envs(ge), envs)
     np.testing.assert_array_equal(env.get_state(), O.get_state(planes))

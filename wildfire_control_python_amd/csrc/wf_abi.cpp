@@ -430,6 +430,25 @@ void drop_graphs(wf_ctx *c)
     c->graphs.clear();
 }
 
+// How a single step of a split context goes out.  Default: n_parts part launches of the kernel wf_pick_group_for sizes.
+// One generation of waves on the reference's 14x14 grid (round 4, profiles/r04_group_shared_sweep.txt and r04_experiments.txt: 48 combinations
+// of group size x shared agent phases x parts, twice): 4 environments per wave, phases A and C shared by the 4 waves of a workgroup,
+// THREE part launches - 19.4-19.7 against 19.9-20.2 us per 65 536-env step, 13.9 against 15.7 at 40 960, 22.6 against 23.6 at 81 920;
+// no gain on 10x10 / 12x12, slower from ~100 000 environments up.  WF_NO_ONEGEN=1 switches it off; any explicit WF_GROUP / WF_SHARED / WF_SPLIT wins.
+struct StepShape { int parts, group, shared; };
+StepShape single_step_shape(const wf_ctx *c)
+{
+    StepShape sh = { c->n_parts, c->knobs.group, c->knobs.shared };
+    const bool rare = c->p.allow_dig_toggle || c->p.make_rivers;
+    if (c->fam == WF_FAM_WAVE && c->W == 14 && c->H == 14 && !rare && c->p.wind_mode == WF_WIND_CALM && c->knobs.group <= 0 && !c->knobs.shared &&
+        !c->knobs.split_explicit && !c->knobs.no_rows && !c->knobs.no_onegen && c->n_side >= 2 && c->batch >= 40960 && c->batch <= 90112) {
+        sh.parts = 3;
+        sh.group = 4;
+        sh.shared = 4;
+    }
+    return sh;
+}
+
 // One wf_step*_device call of the wave family: the launches, on the context's stream(s).
 int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t update_mask, double *d_reward, uint8_t *d_done, int8_t *d_obs)
 {
@@ -478,7 +497,14 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
         }
         // independent parts of the batch on separate streams (inputs must be complete when this is
         // called: the context's own streams are not ordered with the caller's streams)
-        const int parts = tparts > 1 ? tparts : c->n_parts;
+        WfKnobs kp = kn;
+        int parts = tparts > 1 ? tparts : c->n_parts;
+        if (tparts <= 1 && a.n_steps == 1) {               // a single step (also each step of an n-step call issued as single steps)
+            const StepShape sh = single_step_shape(c);
+            parts = sh.parts;
+            a.group = sh.group;
+            kp.shared = sh.shared;
+        }
         {
             const int rc = begin_split(c, parts);
             if (rc != WF_OK) return rc;
@@ -500,7 +526,7 @@ int wave_step_issue(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t up
             if (a.reward) ai.reward = a.reward + lo;
             if (a.done) ai.done = a.done + lo;
             if (a.obs) ai.obs = a.obs + (size_t)lo * cells * 3;
-            HIP_TRY(c, wf_launch_step(c->fam, ai, kn, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
+            HIP_TRY(c, wf_launch_step(c->fam, ai, kp, i == 0 ? c->stream : c->side[i - 1], c->num_cus));
         }
         c->side_pending = true;
     }
@@ -1158,11 +1184,15 @@ const char *wf_step_kernel_name(const wf_ctx *c)
 {
     if (!c) return "none";
     WfArgs a = base_args(c);
+    WfKnobs kn = c->knobs;
     if (splits(c, 1)) {
+        const StepShape sh = single_step_shape(c);
+        a.group = sh.group;
+        kn.shared = sh.shared;
         if (a.group <= 0) a.group = wf_pick_group_for(c->W, c->H, c->num_cus, c->batch, c->knobs);
-        a.batch = split_per(c);
+        a.batch = split_per(c, sh.parts);
     }
-    return wf_single_step_kernel(c->fam, a, c->knobs, c->num_cus);
+    return wf_single_step_kernel(c->fam, a, kn, c->num_cus);
 }
 
 const char *wf_call_kernel_name(const wf_ctx *c, int n_steps)
@@ -1188,7 +1218,7 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
 {
     if (!c || n_steps < 1) return 0;
     if (c->fam != WF_FAM_WAVE) return n_steps * (splits_big(c) ? c->n_parts : 1);      // launch sequences
-    const int per_step = splits(c, 1) ? c->n_parts : 1;
+    const int per_step = splits(c, 1) ? single_step_shape(c).parts : 1;
     if (n_steps == 1) return per_step;
     if (c->p.wind_mode != WF_WIND_CALM) return per_step * n_steps;                      // wind: single-step launches only
     const int tp = ticks_parts(c) > 1 ? ticks_parts(c) : 1;                             // wf_step_ticks: one launch, or a few parts
@@ -1198,7 +1228,7 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
     }
     const bool rows_loop = multi_rows_call(c, n_steps);
     if (ticks_serves_split(c, true, rows_loop)) return tp;                              // (a call with actions, as above)
-    return rows_loop ? c->n_parts : c->n_parts * n_steps;
+    return rows_loop ? c->n_parts : per_step * n_steps;
 }
 
 #ifdef WF_WAVE_TIMING
@@ -1224,7 +1254,9 @@ int wf_reload_env(wf_ctx *c)
 
 int wf_step_launches(const wf_ctx *c)
 {
-    return c ? ((splits(c, 1) || splits_big(c)) ? c->n_parts : 1) : 0;
+    if (!c) return 0;
+    if (splits(c, 1)) return single_step_shape(c).parts;
+    return splits_big(c) ? c->n_parts : 1;
 }
 
 }  // extern "C"

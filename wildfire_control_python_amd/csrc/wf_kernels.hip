@@ -658,6 +658,7 @@ void wf_read_knobs(WfKnobs *k)
     k->whole_batch = 0;
     k->ticks_lds = num("WF_TICKS_LDS", 0);
     k->no_prio = set("WF_NO_PRIO");
+    k->no_onegen = set("WF_NO_ONEGEN");
 }
 
 // environments per wave iteration of the shape's rows-layout kernel (0: the shape has none, or WF_NO_ROWS)
