@@ -45,6 +45,9 @@ __device__ __forceinline__ uint32_t type_of(uint32_t tp, uint32_t q)
 #ifndef WF_PROGRESS_PRIO
 #define WF_PROGRESS_PRIO 0   // rows kernel: a wave lowers its issue priority as it gets ahead (see set_progress_prio; measured: off is faster)
 #endif
+#ifndef WF_SHARED_A_PRIO
+#define WF_SHARED_A_PRIO 1   // workgroup-shared rows kernel: issue priority of the wave that runs phase A (see wf_step_rows)
+#endif
 #ifndef WF_ROWS_WAVES_MIN
 #define WF_ROWS_WAVES_MIN WF_LB_ROWS   // see wf_step_rows
 #endif
