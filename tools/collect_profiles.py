@@ -12,12 +12,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/prof_{tag}"
 
 RUNS = [  # (directory, what was run)
-    ("kt_c3", "python3 bench.py --no-cpu-baseline   (default run, 65 536 x 14x14: a step = 2 concurrent half-batch launches of "
+    ("kt_c3", "python3 bench.py --no-cpu-baseline   (default run, 65 536 x 14x14: a step = 3 concurrent part launches (rounds 1-3: 2 half-batch launches) of "
               "wf_step_rows, so their durations overlap; the calls also hold the extra legs' launches: c2 / c4 / c5_shard / hbm_1m)"),
     ("kt_c3_single", "WF_NO_SPLIT=1 python3 bench.py --no-extras --no-cpu-baseline   (65 536 x 14x14, ONE launch per step: compare "
                      "AverageNs with roofline.single_launch.launch_us of the bench line)"),
-    ("kt_c3_split", "python3 bench.py --no-extras --no-cpu-baseline --steps 1500 --warmup 100   (65 536 x 14x14, the DEFAULT step: two concurrent "
-                    "half-batch launches per step on two streams - a launch lasts about one step period because the two share the chip; "
+    ("kt_c3_split", "python3 bench.py --no-extras --no-cpu-baseline --steps 1500 --warmup 100   (65 536 x 14x14, the DEFAULT step: three concurrent "
+                    "part launches per step on three streams - a launch lasts about one step period because the parts share the chip; "
                     "the per-launch records are summarised in profiles/<tag>_c3_split_trace.json)"),
     ("kt_c5", "python3 bench.py --no-extras --no-cpu-baseline --batch 125000 --steps 400 --warmup 40   (one shard of BASELINE configs[4])"),
     ("kt_c4", "python3 bench.py --no-extras --no-cpu-baseline --size 256 --batch 1024 --noop --ignite-ppm 10000 --steps 200 --warmup 20"

@@ -1,5 +1,5 @@
-"""Per-launch view of a rocprofv3 --kernel-trace run of the default (split) headline step: the step is two concurrent
-launches of wf_step_rows on two streams, so per-kernel statistics alone cannot show the step period.  From the
+"""Per-launch view of a rocprofv3 --kernel-trace run of the default (split) headline step: the step is two (round 4: three)
+concurrent part launches of wf_step_rows on as many streams, so per-kernel statistics alone cannot show the step period.  From the
 dispatch records (start / end timestamps per launch, queue id) this prints, and stores as JSON:
   * per queue: launches, mean / median duration, median start-to-start period
   * the step period = median distance between consecutive launches of the same queue (one launch per queue and step)
@@ -46,8 +46,9 @@ for i, r in enumerate(steady):
 res["mean_fraction_of_a_launch_overlapped_by_the_other_stream"] = statistics.mean(ov)
 res["algorithmic_bytes_per_step"] = 65536 * 196 * 8
 res["frac_of_8TBs_from_the_period"] = res["algorithmic_bytes_per_step"] / (res["step_period_us_median"] * 1e-6) / 8e12
-res["note"] = ("one step = one launch on EACH queue (two half-batch launches of 32 768 environments); a launch lasts about as long as the "
-               "step period because the two share the chip; the period, not the launch duration, is the time per step")
+res["part_launches_per_step"] = len(byq)
+res["note"] = (f"one step = one launch on EACH of the {len(byq)} queues (part launches over equal shares of the 65 536 environments); a launch lasts "
+               "about as long as the step period because the parts share the chip; the period, not the launch duration, is the time per step")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 3:
