@@ -84,7 +84,6 @@ struct WfKnobs {
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
-    int ticks_lds;   // WF_TICKS_LDS (experiment): bytes of unused dynamic LDS per wf_step_ticks workgroup, to cap the workgroups a CU takes
     int no_onegen;   // WF_NO_ONEGEN: never the one-generation shape of a single step (4 environments per wave, shared agent phases, 3 parts; wf_abi.cpp: single_step_shape)
     int no_prio;     // WF_NO_PRIO: never set WF_HOT_PROGRESS_PRIO
     int whole_batch; // per call (not an environment switch): this launch steps the whole batch alone (no part launches beside it)

@@ -283,8 +283,8 @@ hipError_t wf_launch_nstep_wave(const WfArgs &a, const WfKnobs &k, hipStream_t s
             if (rare) hipLaunchKernelGGL((wf_step_wave<w, h, true, true>), dim3(blocks), dim3(256), 0, s, a);            \
             else hipLaunchKernelGGL((wf_step_wave<w, h, true, false>), dim3(blocks), dim3(256), 0, s, a);                \
         } else {                                                                                                         \
-            if (rare) hipLaunchKernelGGL((wf_step_ticks<w, h, true>), dim3(blocks), dim3(256), k.ticks_lds, s, a);       \
-            else hipLaunchKernelGGL((wf_step_ticks<w, h, false>), dim3(blocks), dim3(256), k.ticks_lds, s, a);           \
+            if (rare) hipLaunchKernelGGL((wf_step_ticks<w, h, true>), dim3(blocks), dim3(256), 0, s, a);                 \
+            else hipLaunchKernelGGL((wf_step_ticks<w, h, false>), dim3(blocks), dim3(256), 0, s, a);                     \
         }                                                                                                                \
         return hipGetLastError();                                                                                        \
     }
@@ -656,7 +656,6 @@ void wf_read_knobs(WfKnobs *k)
     k->split_explicit = set("WF_SPLIT") ? 1 : 0;
     k->multi_rows = 0;
     k->whole_batch = 0;
-    k->ticks_lds = num("WF_TICKS_LDS", 0);
     k->no_prio = set("WF_NO_PRIO");
     k->no_onegen = set("WF_NO_ONEGEN");
 }

@@ -488,10 +488,6 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? WF_LB_ROWS_MULTI : WF_ROWS_WAVES_MIN,
                         chg |= dd;
                     }
                     u64 IGNANY = 0, IGN0 = 0, IGNL = 0;
-#ifdef WF_EXP_SKIP_HEAT      // timing experiment only (wrong results): the heat / ignition pass left out - is the kernel bound by instruction issue?
-                    static_for<CPL>([&](auto J) { constexpr int j = decltype(J)::value; FIREALL |= STILL[j]; HITS |= STILL[j] & RBG[j]; });
-                    if (false)
-#endif
                     static_for<CPL>([&](auto J) {
                         constexpr int j = decltype(J)::value;
                         // get_neighbours radius 1 (:311-326) + apply_heat_from_to (:278-294): burning neighbours

@@ -61,9 +61,6 @@ __global__ __launch_bounds__(256, WF_TICKS_LB) void wf_step_ticks(const WfArgs a
     const uint32_t lane = __lane_id();
     // EXEC = the lanes that own cells, for the whole kernel: idle lanes never load, store or put bits into a ballot
     if (lane >= (uint32_t)LANES) return;
-#ifdef WF_EXP_STAGGER        // timing experiment: every other workgroup starts WF_EXP_STAGGER x 64 cycles late (are waves in lockstep the cost?)
-    if (blockIdx.x & 1u) __builtin_amdgcn_s_sleep(WF_EXP_STAGGER);
-#endif
     const uint32_t wave0 = rfl(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t nwaves = gridDim.x * 4u;
     const uint32_t batch = (uint32_t)a.batch;
