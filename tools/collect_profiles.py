@@ -57,6 +57,8 @@ def counters(d):
 
 lines, vals = [], {}
 for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
+                        ("c3parts", "wf_step_rows", "65 536 x 14x14, the DEFAULT step: three part launches of the workgroup-shared instantiation (--steps 40 --warmup 400; "
+                                                    "under --pmc the parts run one after the other; the means are per PART launch, a step is three of them)"),
                         ("c4", "wf_step_tiled", "1 024 x 256x256 (268 MB; WF_NO_SPLIT=1, ticks 60..120 after the reset, --min-ms 0)"),
                         ("hbm", "wf_step_rows", "1 048 576 x 14x14 (822 MB; WF_NO_SPLIT=1, steps 60..100, --min-ms 0)"),
                         ("c5", "wf_step_rows", "125 000 x 14x14 (98 MB, one shard of configs[4]; WF_NO_SPLIT=1, --steps 40 --warmup 400)"),
@@ -94,6 +96,16 @@ def traffic(cfg, kernel, cells, workload):
 
 t = traffic("c3", "wf_step_rows<14,14,2,false>", 65536 * 196,
             "65536 x 14x14, bench.py default (counters collected with one launch per step, steady state)")
+# the default step since round 4: three part launches (counters per launch -> x 3 per step); the single-launch figures stay beside it
+t_single = dict(t)
+tp = traffic("c3parts", "wf_step_rows<14,14,2,true> x3", 65536 * 196,
+             "65536 x 14x14, bench.py default: a step = three part launches (counters per part launch, summed over the three)")
+for k in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "read_bytes_uncorrected", "read_bytes_corrected", "write_bytes", "traffic_bytes_per_launch",
+          "read_over_state", "written_over_state"):
+    tp[k] *= 3
+tp["part_launches_per_step"] = 3
+t = tp
+t["single_launch"] = t_single
 t["round"] = int(tag[1:])
 t["note"] = ("separate --pmc passes (profiles/%s_pmc_summary.txt).  FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md - "
              "which is documented for 16-B-per-lane streaming loads; these are 28-byte-stride dwordx4 + dwordx3 loads, so the uncorrected "
@@ -113,10 +125,10 @@ t["other_sizes"]["mid_64"] = traffic("mid", "wf_step_tiled", 4096 * 4096, "4096 
 # what bench.py looks up, per leg of its JSON line; every entry names the PMC pass it came from
 t["kernel_source_sha256"] = open(f"{src}/kernel_source_sha256.txt").read().strip()
 t["legs"] = {}
-for leg, key, cfg in (("c3", None, "c3"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5"), ("c2", "c2", "c2"),
+for leg, key, cfg in (("c3", None, "c3parts"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5"), ("c2", "c2", "c2"),
                       ("c3_wind", "c3_wind", "wind"), ("mid_64", "mid_64", "mid")):
     e = dict(t if key is None else t["other_sizes"][key])
-    for k in ("other_sizes", "legs", "note", "round", "kernel_source_sha256"):
+    for k in ("other_sizes", "legs", "note", "round", "kernel_source_sha256", "single_launch"):
         e.pop(k, None)
     e["pmc_pass"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gpurun_out/prof_{tag}/pmc_{cfg}_*, "
                      f"summary in profiles/{tag}_pmc_summary.txt")

@@ -47,8 +47,16 @@ res["mean_fraction_of_a_launch_overlapped_by_the_other_stream"] = statistics.mea
 res["algorithmic_bytes_per_step"] = 65536 * 196 * 8
 res["frac_of_8TBs_from_the_period"] = res["algorithmic_bytes_per_step"] / (res["step_period_us_median"] * 1e-6) / 8e12
 res["part_launches_per_step"] = len(byq)
+# Under rocprofv3 every dispatch costs the HOST about 10 us (measured: three queues, 31.2 us from launch to launch of a queue =
+# 10.4 us per launch).  Where launches per step x that cost exceeds the un-profiled step time, the period in this trace is the
+# profiler's, not the kernel's: the launches are then shorter than the period and overlap less.
+med_dur = statistics.median([(r["e"] - r["s"]) / 1e3 for r in steady])
+res["host_issue_interval_us"] = res["step_period_us_median"] / len(byq)
+res["period_is_the_profilers"] = bool(res["step_period_us_median"] > 1.15 * med_dur)
 res["note"] = (f"one step = one launch on EACH of the {len(byq)} queues (part launches over equal shares of the 65 536 environments); a launch lasts "
-               "about as long as the step period because the parts share the chip; the period, not the launch duration, is the time per step")
+               "about as long as the step period because the parts share the chip; the period, not the launch duration, is the time per step - "
+               "unless period_is_the_profilers: then the host, slowed by the profiler to one launch per host_issue_interval_us, is what sets the period, "
+               "and the step time has to be taken from bench.py's HIP events (roofline.launch_us)")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 3:

@@ -46,6 +46,11 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_IN
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_c2_insts -- $C2 > $out/pmc_c2_insts.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_c3_active -- $B $PM > $out/pmc_c3_active.log 2>&1
 unset WF_NO_SPLIT
+# the DEFAULT headline step (three part launches of the workgroup-shared instantiation; under --pmc they run one after the other:
+# the counters are per part launch, a step is their sum)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_c3parts_$c -- $B $PM > $out/pmc_c3parts_$c.log 2>&1
+done
 python3 tools/c4_write_amp.py > $out/c4_write_amp.json 2> $out/c4_write_amp.err
 # ---- the same bench un-profiled, for the agreement check
 python3 bench.py > $out/bench_plain.json 2> $out/bench_plain.err
