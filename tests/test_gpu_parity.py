@@ -6,6 +6,8 @@ compared bit-exactly (integer planes, scalars, float64 rewards) with
   * the CPU oracle on the same seeded inputs,
 and at BASELINE.json's full sizes through size-independent properties.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -2230,6 +2232,18 @@ def test_alternating_sweeps_of_the_rows_kernel_change_nothing(wf, monkeypatch):
                 ro[stopped], do[stopped] = 0.0, 0
             np.testing.assert_array_equal(ra[t][0][lo:lo + 2048], ro, err_msg=f"oracle reward step {t} envs {lo}..")
         np.testing.assert_array_equal(pa[lo:lo + 2048], planes, err_msg=f"oracle planes envs {lo}..")
+
+
+def test_torch_can_be_imported_after_the_library():
+    """PyTorch's ROCm wheels bundle their own HIP runtime; two copies in one process do not share the device, and the one that
+    initialises second finds no GPU.  The loader therefore maps torch's copy first when torch is installed (without importing
+    torch): a fresh process that creates a context, steps it and only THEN imports torch and uses the GPU through it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "import_order_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "torch after the library: 8.0" in out.stdout, out.stdout
 
 
 # ------------------------------------------------ rows layout with an odd number of environments per iteration

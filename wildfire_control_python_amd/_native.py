@@ -99,6 +99,26 @@ SYMBOLS = [
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels bundle their own HIP / HSA runtime under torch/lib.  Two copies of the runtime in one process do not
+    share the device: whichever initialises second finds "No HIP GPUs".  When torch is installed but not imported yet, its copy
+    is loaded here (located with find_spec: torch itself is NOT imported), so that this library's libamdhip64 dependency
+    resolves to the copy torch will use later and `import torch` after this package works as it does before it.  Without
+    torch (a plain C client, a torch-free Python process) the system runtime under /opt/rocm is used as linked."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("WILDFIRE_NO_TORCH_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libwildfire_hip.so (built by wildfire_control_python_amd/csrc/Makefile)."""
     global _lib
@@ -107,6 +127,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C {os.path.join(HERE, 'csrc')}` "
                 "(or __graft_entry__.build()).  The wildfire step has no CPU fallback.")
+        _share_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
