@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline loop only: no fused / observation / host-API / single-launch / config legs (profiling passes)")
-    ap.add_argument("--legs", default="c2,c4,c5_shard,hbm_1m,c3_wind,mid_64", help="extra config legs to run (comma separated)")
+    ap.add_argument("--legs", default="c2,c2_n64,c4,c5_shard,hbm_1m,c3_wind,mid_64", help="extra config legs to run (comma separated)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--ignite-ppm", type=int, default=0, help="extra pre-ignited cells per million at reset (config 4)")
@@ -259,7 +259,7 @@ def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call
     cells = B * S * S
     us = ms / steps * 1e3
     achieved = BYTES_PER_CELL_UPDATE * cells * n / (us * 1e-6) / 1e9
-    traffic, traffic_note = measured_traffic(name, BYTES_PER_CELL_UPDATE * cells * n)
+    traffic, traffic_note = measured_traffic(name, BYTES_PER_CELL_UPDATE * cells * n) if name != "c2_n64" else (None, "no counter pass for this informational leg")
     get_state = None
     if name == "c4":
         # World.get_state() of the whole batch as its own call (what reset() returns; the step kernels write it themselves)
@@ -520,6 +520,8 @@ def main():
         want = [x for x in args.legs.split(",") if x]
         specs = {
             "c2": dict(S=10, B=4096, noop=True, steps=200, warmup=10, ticks_per_call=16),
+            # (informational: the same configuration at the API's maximum of 64 ticks per call - the call's fixed cost spread over four times the ticks)
+            "c2_n64": dict(S=10, B=4096, noop=True, steps=100, warmup=5, ticks_per_call=64),
             "c4": dict(S=256, B=1024, noop=True, ppm=10000, steps=200, warmup=20),
             "c5_shard": dict(S=14, B=125000, noop=False, env_id0=875000, steps=400, warmup=40),
             "hbm_1m": dict(S=14, B=1048576, noop=False, steps=120, warmup=20),
