@@ -256,8 +256,8 @@ class ForestFire:
         if not self.W.RUNNING and not self.W.agents and encode_action(action) < 4:
             # the reference indexes W.agents[0] here and raises IndexError (forest_fire.py:33)
             raise IndexError("list index out of range")
-        a = np.array([encode_action(action)], dtype=np.int8)
-        reward, _, planes, envs = self._b.step_download(a)       # the step and the state it leaves, one synchronisation
+        # the step and the state it leaves, one synchronisation, into buffers the batched object keeps
+        reward, _, planes, envs = self._b.step_download_reuse(encode_action(action))
         r = float(reward[0])
         self.W._last_reward = int(r) if r == int(r) and r in (
             self.METADATA["default_reward"], self.METADATA["death_penalty"],
