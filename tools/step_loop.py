@@ -17,8 +17,11 @@ ap.add_argument("--n", type=int, default=1)
 ap.add_argument("--calls", type=int, default=400)
 ap.add_argument("--warm", type=int, default=400, help="untimed steps before the timed calls (episodes in steady state)")
 ap.add_argument("--noop", action="store_true")
+ap.add_argument("--fuel", default="10,40", help="fuel range lo,hi")
+ap.add_argument("--no-containment", action="store_true")
 a = ap.parse_args()
-env = pkg.BatchedForestFire(a.batch, size=a.size, seed=1234, auto_reset=True, fuel_range=(10, 40))
+lo, hi = (int(x) for x in a.fuel.split(","))
+env = pkg.BatchedForestFire(a.batch, size=a.size, seed=1234, auto_reset=True, fuel_range=(lo, hi), containment=(False if a.no_containment else None))
 env.reset(seed=1234)
 T, B = a.n, a.batch
 rows = 64
