@@ -307,7 +307,10 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               # small grids the tiled family can serve go to the generic one (faster below 32x32); WF_FAMILY=tiled keeps
               # the tiled kernels covered there (marked by B + 10000); packed strips: 4 per wave up to W = 64, 2 up to 128
               (24, 24, 10096), (32, 20, 10064), (48, 48, 24), (64, 100, 12), (128, 128, 6), (36, 30, 40),
-              (64, 300, 6), (128, 200, 4), (100, 140, 4)]          # packed strips AND several workgroups per environment
+              (64, 300, 6), (128, 200, 4), (100, 140, 4),          # packed strips AND several workgroups per environment
+              # grids ONE tiled workgroup covers step in one launch (wf_step_tiled<solo>: every tiled shape above but
+              # 256x70, 256x256 and the last three); WF_NO_SOLO=1 keeps the two-launch form covered there (B + 20000)
+              (64, 64, 20024), (128, 128, 20006), (64, 100, 20012), (32, 20, 30064)]
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)
@@ -317,6 +320,11 @@ def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
     if B < 0:
         monkeypatch.setenv("WF_CELLS_LEGACY", "1")
         B = -B
+    monkeypatch.delenv("WF_NO_SOLO", raising=False)
+    no_solo = B > 20000
+    if no_solo:
+        monkeypatch.setenv("WF_NO_SOLO", "1")
+        B -= 20000
     if B > 10000:
         monkeypatch.setenv("WF_FAMILY", "tiled")
         B -= 10000
@@ -329,6 +337,9 @@ def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
     if "cells" in env.kernel_name:
         legacy = "WF_CELLS_LEGACY" in __import__("os").environ or (W * H > 1024 and B < 512)
         assert env.step_kernel == ("wf_step_cells" if legacy else "wf_step_env")
+    if "tiled" in env.kernel_name:
+        solo = not no_solo and (W, H) not in ((256, 70), (256, 256), (64, 300), (128, 200), (100, 140))
+        assert env.step_kernel == ("wf_step_tiled<solo>" if solo else "wf_step_tiled"), env.step_kernel
     assert env.containment                                       # both big-grid families test containment
     env.reset(seed=123)
     op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=int(env.containment))

@@ -301,6 +301,12 @@ bool splits(const wf_ctx *c, int n_steps)
            !c->knobs.no_split && !c->sync_call;
 }
 
+// the tiled family's one-launch step (wf_step_tiled<.., SOLO>): grids one of its workgroups covers
+bool tiled_solo(const wf_ctx *c)
+{
+    return c->fam == WF_FAM_TILED && !c->knobs.no_solo && wf_tiled_solo(c->H, c->W);
+}
+
 bool splits_big(const wf_ctx *c)
 {
     return c->fam != WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && c->batch >= 2 * c->n_parts &&
@@ -973,7 +979,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
             u64 *halo = c->d_halo ? c->d_halo + (size_t)lo * wf_tiled_groups(c->H, c->W) * 8 : nullptr;
             hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
             HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 4, halo, c->p.seed, si,
-                                          c->fam == WF_FAM_CELLS && wf_cells_per_env_kernel(c->batch, c->H, c->W, c->knobs)));
+                                          c->fam == WF_FAM_CELLS && wf_cells_per_env_kernel(c->batch, c->H, c->W, c->knobs), tiled_solo(c)));
             if (want_obs && !fused_obs)
                 HIP_TRY(c, wf_launch_get_state(a.planes_out, d_obs + (size_t)lo * cells * 3, hi - lo, c->H, c->W, si));
         }

@@ -84,6 +84,7 @@ struct WfKnobs {
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
+    int no_solo;     // WF_NO_SOLO: tiled grids one workgroup covers step as the larger ones do (wf_tiled_prologue -> wf_step_tiled), not in one launch
     int no_onegen;   // WF_NO_ONEGEN: never the one-generation shape of a single step (4 environments per wave, shared agent phases, 3 parts; wf_abi.cpp: single_step_shape)
     int no_prio;     // WF_NO_PRIO: never set WF_HOT_PROGRESS_PRIO
     int whole_batch; // per call (not an environment switch): this launch steps the whole batch alone (no part launches beside it)
@@ -131,7 +132,9 @@ hipError_t wf_launch_nstep_wave(const WfArgs &a, const WfKnobs &k, hipStream_t s
 // halo != nullptr (tiled family): the step runs IN PLACE (planes_out == planes); halo = u64[batch][gx][8] scratch
 // generic family's part of wf_launch_step_big (wf_generic.hip)
 hipError_t wf_launch_step_generic(const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 auto_seed, hipStream_t s, bool per_env);
-hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env);
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env,
+                              bool solo);
+bool wf_tiled_solo(int H, int W);    // one workgroup of wf_step_tiled covers an environment: the whole step can be that one launch
 #define WF_RIVER_MAX_H 2048       // big-grid families: rows of a grid whose river fits the reset kernel's LDS row table
 #define WF_CELLS_FLOOD_MAX 60000   // generic family: cells of a grid whose reachability byte board fits the flood kernel's LDS
 // generic family: wf_big_pre -> wf_step_env instead of the five-launch sequence (decided for the context's whole batch)

@@ -115,12 +115,18 @@ struct Pack {
     uint32_t ql;             // this lane's quad within the row
     bool col_ok;             // the quad exists (ql < W / 4)
     bool rivers;             // the context was created with make_rivers: WF_FIRE_BLOCKED cells can exist
+    bool rare;               // ... or with the dig toggle too: cells that burn without being passable can exist
     u64 XL;                  // lane of the quad holding x == W-1, in every segment
 };
 
-template <bool STEP, bool REACH, bool OBS, int P>
+// REACH: 0 no containment test this step; 1 burning cells are tested against the environment's reachability board;
+// 2 (one workgroup per environment, board to be rebuilt): the row's masks are COLLECTED for the flood that follows the
+// sweep - slot[0..3] passable before the tick, [4..7] burning after it, [8..11] burning-but-impassable before it.
+enum { REACH_NONE = 0, REACH_TEST = 1, REACH_COLLECT = 2, COLLECT_WORDS = 12 };
+
+template <bool STEP, int REACH, bool OBS, int P>
 __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, uint32_t ign, const Pack<P> &pk, const uint4 &cur,
-                                          const u64 (&Sp)[4], const u64 (&Sc)[4], const u64 (&Sn)[4], const u64 *reach_e,
+                                          const u64 (&Sp)[4], const u64 (&Sc)[4], const u64 (&Sn)[4], const u64 *reach_e, u64 *slot,
                                           const TiledDst &dst, const ObsTile &ot, TiledAcc &A)
 {
     const uint32_t row = r + pk.row_off;
@@ -169,7 +175,21 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
             GR[j] = __ballot((c[j] & 0xffu) == (uint32_t)WF_GRASS);
         }
     }
-    if constexpr (REACH) {   // does a burning cell sit on a border-connected cell?
+    if constexpr (REACH == REACH_COLLECT) {
+        const uint32_t t0[4] = { cur.x, cur.y, cur.z, cur.w };      // (idle lanes hold inert dirt: neither passable nor burning)
+        u64 PS[4], Z[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PS[j] = __ballot((t0[j] & 0xffu) < (uint32_t)WF_DIRT);
+        if (pk.rare) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Z[j] = __ballot(blocked_burning(t0[j]));
+        }
+        if (__lane_id() == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { slot[j] = PS[j]; slot[4 + j] = FIRE[j]; slot[8 + j] = Z[j]; }
+        }
+    }
+    if constexpr (REACH == REACH_TEST) {   // does a burning cell sit on a border-connected cell?
         typedef u64 u64x4 __attribute__((ext_vector_type(4)));
         typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
         u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
@@ -193,10 +213,10 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
     }
 }
 
-template <bool STEP, bool REACH, bool OBS, int P>
+template <bool STEP, int REACH, bool OBS, int P>
 __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, const Pack<P> &pk,
                                             const uint4 *src, const TiledDst &dst, const ObsTile &ot, const uint4 &first, const u64 (&Sf)[4],
-                                            const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, TiledAcc &A)
+                                            const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, u64 *collect, TiledAcc &A)
 {
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
     uint4 C[3] = { first, inert, inert };
@@ -218,7 +238,7 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Sn[j] = Sbelow[j];
                 }
-                tiled_row<STEP, REACH, OBS, P>(rr, H, LW, ign, pk, C[k], M[kp], M[k], Sn, reach_e, dst, ot, A);
+                tiled_row<STEP, REACH, OBS, P>(rr, H, LW, ign, pk, C[k], M[kp], M[k], Sn, reach_e, collect + (rr - r0) * (uint32_t)COLLECT_WORDS, dst, ot, A);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) M[kn][j] = Sn[j];
             }
@@ -226,13 +246,88 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
     }
 }
 
+// The border-reachability board of ONE environment, rebuilt by the environment's own (only) workgroup behind its sweep
+// from the masks the sweep collected (REACH_COLLECT; `collect`: [wave][16 sweep positions][COLLECT_WORDS]) - no cell is
+// read a second time.  `area`: LDS, (H * NW + 4 H) words: the linear reach bitmaps, then the linear passable bitmaps
+// which the board in the tick's interleaved layout replaces once the relaxation is through.  Same board, bit for bit,
+// as wf_tiled_prologue's: bit l of word [r][j] = cell (row r, x = 4l + j) is 4-connected to a passable border cell
+// through passable cells, or burns impassably next to such a cell.  Returns, to every thread: bit 0 a cell that burns
+// after the tick is on the board, bit 1 the relaxation converged (the board may be trusted by later steps).
+template <int P>
+__device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e, const u64 *collect, u64 *area, uint32_t *changed)
+{
+    constexpr int NW = 4 / P;                                    // words of a linear row bitmap: W <= 64 * NW
+    constexpr uint32_t LWP = Pack<P>::LWP, WR = (uint32_t)P * (uint32_t)TR;
+    const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, t = threadIdx.x, nt = blockDim.x;
+    u64 *reach = area, *pass = area + H * NW, *board = pass;
+    // mask `kind` of row r, component j, bit l = quad l of the row (a wave's ballots hold P rows, LWP lanes apart)
+    auto row_mask = [&](uint32_t r, uint32_t kind, uint32_t j) -> u64 {
+        const uint32_t rr = r % WR;
+        const u64 m = collect[((r / WR) * (uint32_t)TR + rr % (uint32_t)TR) * (uint32_t)COLLECT_WORDS + kind * 4u + j];
+        return P == 1 ? m : (m >> ((rr / (uint32_t)TR) * LWP)) & Pack<P>::SEG0;
+    };
+    // passable cells, LINEAR for the run fill (bit x % 64 of word [r][x / 64]), and the seeds: passable border cells
+    for (uint32_t k = t; k < H * NW; k += nt) {
+        const uint32_t r = k / NW, w = k % NW;
+        const u64 lin = spread4(row_mask(r, 0, 0) >> (16u * w)) | (spread4(row_mask(r, 0, 1) >> (16u * w)) << 1) |
+                        (spread4(row_mask(r, 0, 2) >> (16u * w)) << 2) | (spread4(row_mask(r, 0, 3) >> (16u * w)) << 3);
+        u64 bm = r == 0 || r == H - 1 ? ~0ull : 0ull;
+        if (w == 0) bm |= 1ull;
+        if (w == (W - 1u) >> 6) bm |= 1ull << ((W - 1u) & 63u);
+        pass[k] = lin;
+        reach[k] = lin & bm;
+    }
+    __syncthreads();
+    const bool converged = relax_row_bitmaps<NW>(pass, reach, H, H * W, t, nt, changed, [] { __syncthreads(); });
+    // back to the tick's interleaved layout: component j of row r = every fourth bit from bit j
+    for (uint32_t r = t; r < H; r += nt) {
+        u64 il[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const u64 lin = reach[r * NW + w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) il[j] |= squeeze4(lin >> j) << (16 * w);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) board[r * 4 + j] = il[j];
+    }
+    __syncthreads();
+    u64 *out = a.reach + (size_t)e * H * 4;
+    const bool rare = (a.hot_flags & WF_HOT_RARE) != 0;
+    bool hit = false;
+    for (uint32_t k = t; k < H * 4u; k += nt) {
+        const uint32_t r = k >> 2, j = k & 3u;
+        u64 v = board[k];
+        if (rare) {
+            // Burning dirt (WF_DIRT_BURNING) and a fire cell over a river (WF_FIRE_BLOCKED) are impassable, yet the
+            // reference's search starts FROM them: such a cell reaches the border iff one of its 4-neighbours does
+            u64 nb = (r > 0 ? board[k - 4] : 0ull) | (r + 1 < H ? board[k + 4] : 0ull);
+            nb |= j > 0 ? board[k - 1] : (board[k + 3] << 1);
+            nb |= j < 3 ? board[k + 1] : (board[k - 3] >> 1);
+            v |= nb & row_mask(r, 2, j);
+        }
+        out[k] = v;
+        hit |= (v & row_mask(r, 1, j)) != 0;
+    }
+    return (__syncthreads_or(hit ? 1 : 0) ? 1u : 0u) | (converged ? 2u : 0u);
+}
+
 // Workgroup = nw waves (blockDim.x / 64: 4, fewer for grids that need fewer), wave = P strips of 16 rows side by side.
-template <bool OBS, int P>
+// SOLO (grids one workgroup covers, e.g. 64x64 and 128x128): the workgroup does the WHOLE step of its environment -
+// Agent.move / toggle / death by its first thread (big_pre_env, what wf_tiled_prologue does for the larger grids), the
+// tick, the reachability flood when the dig called for one (solo_flood, behind the sweep: only that workgroup is late,
+// not a launch), World.RUNNING / reward / done from reductions in LDS: one launch per step, nothing but the cells, the
+// record and the board touched in memory.
+template <bool OBS, int P, bool SOLO>
 __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer)
 {
     __shared__ u64 halo[4][2][4];                    // [wave][first,last row of each of its segments][component]
     __shared__ uint16_t river_tab[4][64];            // auto-reset with rivers: water column of each of a wave's rows
-    extern __shared__ __attribute__((aligned(16))) uint8_t obs_lds[];     // OBS: [rows of the workgroup][W*3] (+4) staging tile
+    __shared__ uint4 s_ev;                           // SOLO: the environment's record between big_pre_env and big_post_env
+    __shared__ uint32_t s_word[2], s_red[4][2];      // SOLO: step mode, the flood's "changed"; per wave: result bits, healthy cells
+    // [SOLO with the containment test: the sweep's collected masks, nw * 16 * COLLECT_WORDS words]
+    // [OBS: [rows of the workgroup][W*3] (+4) staging tile | solo_flood's area, once the tile has been flushed]
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     constexpr uint32_t LWP = Pack<P>::LWP, WR = (uint32_t)P * (uint32_t)TR;          // lanes per segment, rows per wave
     const uint32_t lane = __lane_id();
     const uint32_t wv = rfl(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -249,10 +344,27 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     pk.ql = P == 1 ? lane : lane % LWP;
     pk.col_ok = pk.ql < LW;
     pk.rivers = (a.hot_flags & WF_HOT_RIVERS) != 0;
+    pk.rare = (a.hot_flags & WF_HOT_RARE) != 0;
     pk.XL = Pack<P>::X0 << (LW - 1u);
     const uint32_t lane_cell0 = pk.row_off * LW + pk.ql;         // this lane's quad index at sweep position 0 (+ r * LW)
     const uint32_t ign = (uint32_t)a.ignite_count;
-    const uint32_t md = mode[e];
+    u64 *const collect = reinterpret_cast<u64 *>(dyn_lds);
+    uint8_t *const obs_lds = dyn_lds + (SOLO && (a.hot_flags & WF_HOT_CONTAINMENT) ? nw * (uint32_t)(TR * COLLECT_WORDS * 8) : 0u);
+    uint32_t md;
+    if constexpr (SOLO) {
+        if (threadIdx.x == 0) {
+            uint4 ev;
+            bool have_record;
+            s_word[0] = big_pre_env(a, e, ev, have_record);
+            s_ev = ev;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the touched bytes, for the other waves of this CU
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        md = rfl(s_word[0]);
+    } else {
+        md = mode[e];
+    }
     const uint32_t wg_row0 = (bid % gx) * nw * WR;
     const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
     int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
@@ -353,15 +465,25 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     }
 
     // ---- sweep
+    u64 *const collect_w = collect + wv * (uint32_t)(TR * COLLECT_WORDS);
+    auto sweep = [&](auto ST, auto RM) {
+        tiled_sweep<decltype(ST)::value, decltype(RM)::value, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, collect_w, A);
+    };
+    typedef std::integral_constant<int, REACH_NONE> RNone;
+    typedef std::integral_constant<int, REACH_TEST> RTest;
+    typedef std::integral_constant<int, SOLO ? REACH_COLLECT : REACH_TEST> RCollect;
+    const bool collecting = SOLO && (md & MODE_FLOOD);                  // (MODE_FLOOD: only ever with MODE_PRECHECK)
     if (step) {
-        if (reach_test) tiled_sweep<true, true, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
-        else tiled_sweep<true, false, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        if (collecting) sweep(std::true_type{}, RCollect{});
+        else if (reach_test) sweep(std::true_type{}, RTest{});
+        else sweep(std::true_type{}, RNone{});
     } else {
-        if (reach_test) tiled_sweep<false, true, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
-        else tiled_sweep<false, false, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, A);
+        if (collecting) sweep(std::false_type{}, RCollect{});
+        else if (reach_test) sweep(std::false_type{}, RTest{});
+        else sweep(std::false_type{}, RNone{});
     }
     A.bhit |= ((A.ign_x0 & Pack<P>::X0) | (A.ign_xl & pk.XL)) ? 1u : 0u;      // x == 0 / x == W-1 columns
-    if (lane == 0) {
+    if (!SOLO && lane == 0) {
         // device-scope atomics are performed at the memory side (the per-XCD L2s are not coherent with each other);
         // the RETURNING forms, consumed, make the wave wait until they have been
         const uint32_t R = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
@@ -371,8 +493,26 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
         asm volatile("" :: "v"(o0), "v"(o1));
     }
     }   // has_rows
+    if (SOLO && lane == 0) {
+        s_red[wv][0] = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
+        s_red[wv][1] = A.healthy;
+    }
     __syncthreads();
     if constexpr (OBS) flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
+    if constexpr (SOLO) {
+        uint32_t fl = 0;
+        if (md & MODE_FLOOD) {
+            if constexpr (OBS) __syncthreads();                   // the flood's boards take the observation tile's place
+            fl = solo_flood<P>(a, e, collect, reinterpret_cast<u64 *>(obs_lds), &s_word[1]);
+        }
+        if (threadIdx.x == 0) {
+            uint32_t Aw = (fl & 1u) << 2, healthy = 0;
+            for (uint32_t w = 0; w < nw; ++w) { Aw |= s_red[w][0]; healthy += s_red[w][1]; }
+            // (a board that did not converge - never, with the H*W bound - would not be trusted later)
+            big_post_env(a, e, md, Aw, healthy, (fl & 2u) ? (uint32_t)WF_F_REACH_VALID : 0u, s_ev);
+        }
+        return;
+    }
     // ---- World.RUNNING / reward / done of the environment: by whichever of its gx workgroups arrives last (every wave
     // of this workgroup has its reduction atomics behind it: the barrier above).  No data but the atomically updated
     // words passes between the workgroups, so no cache write-back fence is needed.
@@ -395,8 +535,18 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
 //      4-connected to a passable border cell through passable cells;
 //   3. the still-burning masks of the two rows just outside every workgroup of wf_step_tiled, taken from the state
 //      BEFORE the tick: halo[(e*gx + g)*8 + 0..3] = row above workgroup g, +4..7 = row below (one wave per row).
+#ifdef WF_DBG_PRO
+__device__ unsigned long long wf_dbg[16];
+#define DBG_T(i) do { if (threadIdx.x == 0) tdbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DBG_T(i)
+#endif
 __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t *mode, u64 *halo, uint32_t rows_per_wg)
 {
+#ifdef WF_DBG_PRO
+    unsigned long long tdbg[8];
+#endif
+    DBG_T(0);
     extern __shared__ u64 lds[];                     // flood: [H*4] pass, [H*4] reach
     __shared__ u64 pm[4][8][4];                      // flood: the interleaved passable masks of a wave's current 8 rows
     __shared__ uint32_t s_mode, changed;
@@ -414,6 +564,7 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t md = s_mode;
+    DBG_T(1);
     const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane;
     if (md & MODE_FLOOD) {                                           // (only set with the containment test on)
         u64 *pass = lds, *reach = lds + words;
@@ -458,9 +609,11 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
+        DBG_T(2);
         const bool converged = relax_row_bitmaps<4>(pass, reach, H, H * W, threadIdx.x, 256u, &changed, [] { __syncthreads(); });
         // back to the tick's interleaved layout, in place: component j of row r = every fourth bit from bit j
         __syncthreads();
+        DBG_T(3);
         for (uint32_t r = threadIdx.x; r < H; r += 256u) {
             u64 lin[4], il[4] = { 0, 0, 0, 0 };
 #pragma unroll
@@ -496,7 +649,20 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
         }
         // (always true with the H*W bound; a board that did not converge would not be trusted later)
         if (threadIdx.x == 0 && converged) ev.y |= (uint32_t)WF_F_REACH_VALID;
+#ifdef WF_DBG_PRO
+        __syncthreads();
+        DBG_T(4);
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 4; ++i) atomicAdd(&wf_dbg[i], tdbg[i + 1] - tdbg[i]);
+            atomicAdd(&wf_dbg[4], 1ull);
+            atomicMax(&wf_dbg[5], tdbg[4] - tdbg[0]);
+            atomicMax(&wf_dbg[6], tdbg[3] - tdbg[2]);
+        }
+#endif
     }
+#ifdef WF_DBG_PRO
+    if (threadIdx.x == 0 && e % 64u == 5u) { atomicAdd(&wf_dbg[8], 64ull); if (!(md & MODE_FLOOD)) atomicAdd(&wf_dbg[9], 64ull * (__builtin_amdgcn_s_memrealtime() - tdbg[0])); }
+#endif
     if (threadIdx.x == 0 && have_record) *reinterpret_cast<uint4 *>(&a.envs[e]) = ev;
     // ---- outer halos
     if ((md & MODE_MASK) != MODE_STEP || !halo) return;
@@ -519,6 +685,16 @@ __global__ __launch_bounds__(256) void wf_tiled_prologue(const WfArgs a, uint8_t
 
 }  // namespace
 
+#ifdef WF_DBG_PRO
+extern "C" __attribute__((visibility("default"))) void wf_debug_read(unsigned long long *out)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_dbg), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = { 0 };
+    hipMemcpyToSymbol(HIP_SYMBOL(wf_dbg), z, sizeof z);
+}
+#endif
+
 // Shape of a wf_step_tiled launch: strips packed side by side per wave, waves per workgroup, workgroups per environment
 struct TiledShape { int P, nw, rows_per_wg, gx; };
 static TiledShape tiled_shape(int H, int W)
@@ -538,8 +714,26 @@ int wf_tiled_groups(int H, int W) { return tiled_shape(H, W).gx; }
 // wf_step_tiled can write the observation itself when the (x, y-run) blocks of obs are 4-byte aligned
 bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 
-hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env)
+// one workgroup of wf_step_tiled covers an environment of this shape: the step is that kernel's SOLO form, one launch
+bool wf_tiled_solo(int H, int W) { return tiled_shape(H, W).gx == 1; }
+
+hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env,
+                              bool solo)
 {
+    if (fam == WF_FAM_TILED && solo) {
+        const TiledShape ts = tiled_shape(a.H, a.W);
+        const bool containment = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
+        const size_t collect_lds = containment ? (size_t)ts.nw * TR * COLLECT_WORDS * 8 : 0;
+        const size_t flood_lds = containment ? ((size_t)a.H * (4 / ts.P) + (size_t)a.H * 4) * 8 : 0;
+        const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * a.W * 3 + 16 : 0;
+        const size_t lds = collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
+        const dim3 grid((unsigned)a.batch), block(64u * (unsigned)ts.nw);
+#define WF_SOLO_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr)
+        if (a.obs) { if (ts.P == 4) WF_SOLO_LAUNCH(true, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(true, 2); else WF_SOLO_LAUNCH(true, 1); }
+        else { if (ts.P == 4) WF_SOLO_LAUNCH(false, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(false, 2); else WF_SOLO_LAUNCH(false, 1); }
+#undef WF_SOLO_LAUNCH
+        return hipGetLastError();
+    }
     if (fam == WF_FAM_TILED) {
         // prologue (agent logic, reachability flood, outer halos) -> the in-place tick, which also writes the fresh
         // grids of environments that are being auto-reset and whose last workgroup per environment does
@@ -552,7 +746,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         (void)auto_seed;       // == cold->p.seed: finished environments are reset by the tick kernel itself
         const dim3 grid(gx * (unsigned)a.batch), block(64u * (unsigned)ts.nw);
         const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * a.W * 3 + 16 : 0;      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
-#define WF_TILED_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P>), grid, block, obs_lds, s, a, mode, acc, (const u64 *)halo)
+#define WF_TILED_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, false>), grid, block, obs_lds, s, a, mode, acc, (const u64 *)halo)
         if (a.obs) { if (ts.P == 4) WF_TILED_LAUNCH(true, 4); else if (ts.P == 2) WF_TILED_LAUNCH(true, 2); else WF_TILED_LAUNCH(true, 1); }
         else { if (ts.P == 4) WF_TILED_LAUNCH(false, 4); else if (ts.P == 2) WF_TILED_LAUNCH(false, 2); else WF_TILED_LAUNCH(false, 1); }
 #undef WF_TILED_LAUNCH
