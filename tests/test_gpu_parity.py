@@ -315,6 +315,19 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)
 def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
+    monkeypatch.delenv("WF_TILED_ROWS", raising=False)
+    _run_big_grid(wf, monkeypatch, W, H, B)
+
+
+@pytest.mark.parametrize("W,H,rows", [(64, 64, 16), (64, 64, 4), (32, 32, 16), (32, 32, 2), (128, 128, 16), (48, 40, 5), (128, 60, 9)])
+def test_one_launch_tiled_step_with_any_strip_height(wf, monkeypatch, W, H, rows):
+    """The one-launch tiled step takes strips of fewer than 16 rows where that suits the job (wf_tiled_solo_rows: small
+    test batches get the short ones); WF_TILED_ROWS picks the height, here the full 16 and odd ones."""
+    monkeypatch.setenv("WF_TILED_ROWS", str(rows))
+    _run_big_grid(wf, monkeypatch, W, H, 20)
+
+
+def _run_big_grid(wf, monkeypatch, W, H, B):
     T = 70
     monkeypatch.delenv("WF_FAMILY", raising=False)
     if B < 0:

@@ -302,9 +302,9 @@ bool splits(const wf_ctx *c, int n_steps)
 }
 
 // the tiled family's one-launch step (wf_step_tiled<.., SOLO>): grids one of its workgroups covers
-bool tiled_solo(const wf_ctx *c)
+int tiled_solo(const wf_ctx *c)
 {
-    return c->fam == WF_FAM_TILED && !c->knobs.no_solo && wf_tiled_solo(c->H, c->W);
+    return c->fam == WF_FAM_TILED && !c->knobs.no_solo ? wf_tiled_solo_rows(c->H, c->W, c->knobs.tiled_rows, c->batch) : 0;
 }
 
 bool splits_big(const wf_ctx *c)

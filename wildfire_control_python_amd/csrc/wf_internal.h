@@ -84,6 +84,7 @@ struct WfKnobs {
     int host_stage_min;  // WF_HOST_STAGE_MIN: host-buffer calls with at least this many actions go through device mirrors (0 = never: measured slower)
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
+    int tiled_rows;  // WF_TILED_ROWS: rows per strip of the one-launch tiled step (default: wf_tiled_solo_rows)
     int no_solo;     // WF_NO_SOLO: tiled grids one workgroup covers step as the larger ones do (wf_tiled_prologue -> wf_step_tiled), not in one launch
     int no_onegen;   // WF_NO_ONEGEN: never the one-generation shape of a single step (4 environments per wave, shared agent phases, 3 parts; wf_abi.cpp: single_step_shape)
     int no_prio;     // WF_NO_PRIO: never set WF_HOT_PROGRESS_PRIO
@@ -133,8 +134,11 @@ hipError_t wf_launch_nstep_wave(const WfArgs &a, const WfKnobs &k, hipStream_t s
 // generic family's part of wf_launch_step_big (wf_generic.hip)
 hipError_t wf_launch_step_generic(const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 auto_seed, hipStream_t s, bool per_env);
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env,
-                              bool solo);
-bool wf_tiled_solo(int H, int W);    // one workgroup of wf_step_tiled covers an environment: the whole step can be that one launch
+                              int solo_rows);
+// rows per strip of the tiled family's one-launch step of this shape (0: the shape needs several workgroups per environment)
+int wf_tiled_solo_rows(int H, int W, int want, int batch);
+#define WF_TILED_MIN_ROWS 8           // ... never shorter than this for the sake of more waves
+#define WF_TILED_SOLO_WAVES 8192      // ... which a job with fewer waves than this (8 per SIMD) gets
 #define WF_RIVER_MAX_H 2048       // big-grid families: rows of a grid whose river fits the reset kernel's LDS row table
 #define WF_CELLS_FLOOD_MAX 60000   // generic family: cells of a grid whose reachability byte board fits the flood kernel's LDS
 // generic family: wf_big_pre -> wf_step_env instead of the five-launch sequence (decided for the context's whole batch)

@@ -659,6 +659,7 @@ void wf_read_knobs(WfKnobs *k)
     k->no_prio = set("WF_NO_PRIO");
     k->no_onegen = set("WF_NO_ONEGEN");
     k->no_solo = set("WF_NO_SOLO");
+    k->tiled_rows = num("WF_TILED_ROWS", 0);
 }
 
 // environments per wave iteration of the shape's rows-layout kernel (0: the shape has none, or WF_NO_ROWS)
@@ -718,7 +719,7 @@ bool wf_multi_step_in_rows(WfFamily fam, const WfArgs &a, const WfKnobs &k, int 
 const char *wf_single_step_kernel(WfFamily fam, const WfArgs &a, const WfKnobs &k, int num_cus)
 {
     static thread_local char buf[64];
-    if (fam == WF_FAM_TILED) return !k.no_solo && wf_tiled_solo(a.H, a.W) ? "wf_step_tiled<solo>" : "wf_step_tiled";
+    if (fam == WF_FAM_TILED) return !k.no_solo && wf_tiled_solo_rows(a.H, a.W, 0, a.batch) ? "wf_step_tiled<solo>" : "wf_step_tiled";
     if (fam == WF_FAM_CELLS) return wf_cells_per_env_kernel(a.batch, a.H, a.W, k) ? "wf_step_env" : "wf_step_cells";
     StepPlan p = { 0, -1 };
     int S = 1;

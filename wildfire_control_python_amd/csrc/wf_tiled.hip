@@ -58,6 +58,9 @@ struct TiledAcc { uint32_t anyfire, bhit, healthy, reach_hit; u64 ign_x0, ign_xl
 #ifndef WF_TILED_STORE_AUX
 #define WF_TILED_STORE_AUX 0
 #endif
+#ifndef WF_TILED_LAZY_BOARD
+#define WF_TILED_LAZY_BOARD 1
+#endif
 struct TiledDst { __amdgpu_buffer_rsrc_t rsrc; uint32_t lane_off; };
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 
@@ -111,7 +114,8 @@ struct Pack {
     static constexpr u64 SEG0 = P == 1 ? ~0ull : ((1ull << (LWP % 64u)) - 1ull);
     static constexpr u64 X0 = P == 1 ? 1ull : P == 2 ? 0x0000000100000001ull : 0x0001000100010001ull;   // first lane of every segment
     static constexpr u64 XE = X0 << (LWP - 1u);                          // last lane of every segment
-    uint32_t row_off;        // this lane's segment * 16: its row at sweep position r is r + row_off
+    uint32_t tr;             // rows per strip (TR; fewer where that gives a small grid's workgroup more waves: tiled_shape)
+    uint32_t row_off;        // this lane's segment * tr: its row at sweep position r is r + row_off
     uint32_t ql;             // this lane's quad within the row
     bool col_ok;             // the quad exists (ql < W / 4)
     bool rivers;             // the context was created with make_rivers: WF_FIRE_BLOCKED cells can exist
@@ -189,14 +193,16 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
             for (int j = 0; j < 4; ++j) { slot[j] = PS[j]; slot[4 + j] = FIRE[j]; slot[8 + j] = Z[j]; }
         }
     }
-    if constexpr (REACH == REACH_TEST) {   // does a burning cell sit on a border-connected cell?
+    // does a burning cell sit on a border-connected cell?  Only "one does" is asked for: the board rows (scalar loads the
+    // sweep would wait for at every row) are fetched for rows that hold fire, until the wave has its first hit
+    if (REACH == REACH_TEST && WF_TILED_LAZY_BOARD ? ((FIRE[0] | FIRE[1] | FIRE[2] | FIRE[3]) != 0 && !A.reach_hit) : REACH == REACH_TEST) {
         typedef u64 u64x4 __attribute__((ext_vector_type(4)));
         typedef const u64x4 __attribute__((address_space(4))) *const_u64x4_ptr;
         u64x4 rb = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)r * 4);
         if constexpr (P > 1) {      // the board rows of the other segments, moved to their lanes (rows past the grid: no fire bit meets them)
 #pragma unroll
             for (int sgm = 1; sgm < P; ++sgm) {
-                const u64x4 rs = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)min(r + (uint32_t)sgm * (uint32_t)TR, H - 1u) * 4);
+                const u64x4 rs = *(const_u64x4_ptr)(uintptr_t)(reach_e + (size_t)min(r + (uint32_t)sgm * pk.tr, H - 1u) * 4);
                 rb |= rs << (u64)(sgm * (int)Pack<P>::LWP);
             }
         }
@@ -254,17 +260,18 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
 // through passable cells, or burns impassably next to such a cell.  Returns, to every thread: bit 0 a cell that burns
 // after the tick is on the board, bit 1 the relaxation converged (the board may be trusted by later steps).
 template <int P>
-__device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e, const u64 *collect, u64 *area, uint32_t *changed)
+__device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e, const uint32_t tr, const u64 *collect, u64 *area, uint32_t *changed)
 {
     constexpr int NW = 4 / P;                                    // words of a linear row bitmap: W <= 64 * NW
-    constexpr uint32_t LWP = Pack<P>::LWP, WR = (uint32_t)P * (uint32_t)TR;
+    constexpr uint32_t LWP = Pack<P>::LWP;
+    const uint32_t WR = (uint32_t)P * tr;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, t = threadIdx.x, nt = blockDim.x;
     u64 *reach = area, *pass = area + H * NW, *board = pass;
     // mask `kind` of row r, component j, bit l = quad l of the row (a wave's ballots hold P rows, LWP lanes apart)
     auto row_mask = [&](uint32_t r, uint32_t kind, uint32_t j) -> u64 {
         const uint32_t rr = r % WR;
-        const u64 m = collect[((r / WR) * (uint32_t)TR + rr % (uint32_t)TR) * (uint32_t)COLLECT_WORDS + kind * 4u + j];
-        return P == 1 ? m : (m >> ((rr / (uint32_t)TR) * LWP)) & Pack<P>::SEG0;
+        const u64 m = collect[((r / WR) * (uint32_t)TR + rr % tr) * (uint32_t)COLLECT_WORDS + kind * 4u + j];
+        return P == 1 ? m : (m >> ((rr / tr) * LWP)) & Pack<P>::SEG0;
     };
     // passable cells, LINEAR for the run fill (bit x % 64 of word [r][x / 64]), and the seeds: passable border cells
     for (uint32_t k = t; k < H * NW; k += nt) {
@@ -319,7 +326,7 @@ __device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e
 // not a launch), World.RUNNING / reward / done from reductions in LDS: one launch per step, nothing but the cells, the
 // record and the board touched in memory.
 template <bool OBS, int P, bool SOLO>
-__global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer)
+__global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer, const uint32_t tr)
 {
     __shared__ u64 halo[4][2][4];                    // [wave][first,last row of each of its segments][component]
     __shared__ uint16_t river_tab[4][64];            // auto-reset with rivers: water column of each of a wave's rows
@@ -328,7 +335,8 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     // [SOLO with the containment test: the sweep's collected masks, nw * 16 * COLLECT_WORDS words]
     // [OBS: [rows of the workgroup][W*3] (+4) staging tile | solo_flood's area, once the tile has been flushed]
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-    constexpr uint32_t LWP = Pack<P>::LWP, WR = (uint32_t)P * (uint32_t)TR;          // lanes per segment, rows per wave
+    constexpr uint32_t LWP = Pack<P>::LWP;                       // lanes per segment
+    const uint32_t WR = (uint32_t)P * tr;                        // rows per wave (tr per strip: TR, fewer for small SOLO grids)
     const uint32_t lane = __lane_id();
     const uint32_t wv = rfl(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
@@ -337,10 +345,11 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const uint32_t bid = a.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
     const uint32_t e = bid / gx;
     const uint32_t r0 = ((bid % gx) * nw + wv) * WR;             // segment 0's first row; segment s: r0 + 16 s
-    const uint32_t r1 = min(r0 + TR, H);                         // end of the sweep (segment 0's rows)
+    const uint32_t r1 = min(r0 + tr, H);                         // end of the sweep (segment 0's rows)
     const bool has_rows = r0 < H;
     Pack<P> pk;
-    pk.row_off = (P == 1 ? 0u : lane / LWP) * (uint32_t)TR;
+    pk.tr = tr;
+    pk.row_off = (P == 1 ? 0u : lane / LWP) * tr;
     pk.ql = P == 1 ? lane : lane % LWP;
     pk.col_ok = pk.ql < LW;
     pk.rivers = (a.hot_flags & WF_HOT_RIVERS) != 0;
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
         uint32_t fl = 0;
         if (md & MODE_FLOOD) {
             if constexpr (OBS) __syncthreads();                   // the flood's boards take the observation tile's place
-            fl = solo_flood<P>(a, e, collect, reinterpret_cast<u64 *>(obs_lds), &s_word[1]);
+            fl = solo_flood<P>(a, e, tr, collect, reinterpret_cast<u64 *>(obs_lds), &s_word[1]);
         }
         if (threadIdx.x == 0) {
             uint32_t Aw = (fl & 1u) << 2, healthy = 0;
@@ -696,13 +705,14 @@ extern "C" __attribute__((visibility("default"))) void wf_debug_read(unsigned lo
 #endif
 
 // Shape of a wf_step_tiled launch: strips packed side by side per wave, waves per workgroup, workgroups per environment
-struct TiledShape { int P, nw, rows_per_wg, gx; };
-static TiledShape tiled_shape(int H, int W)
+struct TiledShape { int P, nw, rows_per_wg, gx, tr; };
+static TiledShape tiled_shape(int H, int W, int tr = TR)
 {
     TiledShape t;
     const int LW = W / 4;
     t.P = LW <= 16 ? 4 : LW <= 32 ? 2 : 1;
-    const int rows_per_wave = t.P * TR;
+    t.tr = tr;
+    const int rows_per_wave = t.P * tr;
     t.nw = (H + rows_per_wave - 1) / rows_per_wave;
     if (t.nw > 4) t.nw = 4;
     t.rows_per_wg = t.nw * rows_per_wave;
@@ -711,24 +721,42 @@ static TiledShape tiled_shape(int H, int W)
 }
 int wf_tiled_groups(int H, int W) { return tiled_shape(H, W).gx; }
 
+// Rows per strip of the one-launch (SOLO) step of `batch` H x W grids, 0 if one workgroup of TR-row strips does not
+// cover such a grid.  The strips are as short as the workgroup's waves allow (a 32x32 grid: four strips of 8 rows side by
+// side in ONE wave - 8 sweep positions, every lane busy - not two of 16; 48x48: four of 12), and a job too small to
+// give every SIMD a few waves takes twice the waves at half the strip (4 096 x 64x64: 24.3 instead of 29.9 us per step;
+// a sweep is serial, so with one or two waves per SIMD it is their latency that shows) - but only then: a wave's
+// fixed part (halo rows, barriers) is worth about five rows (16 384 x 64x64: 83 us per step with 16-row strips, 102
+// with 8).  `want` > 0: the caller's choice (WF_TILED_ROWS), honoured if four waves of such strips cover the grid.
+int wf_tiled_solo_rows(int H, int W, int want, int batch)
+{
+    const TiledShape t = tiled_shape(H, W);
+    if (t.gx != 1) return 0;
+    if (want > 0 && want <= TR && tiled_shape(H, W, want).gx == 1) return want;
+    int nw = t.nw;
+    auto rows = [&](int n) { return (H + t.P * n - 1) / (t.P * n); };
+    while (nw * 2 <= 4 && (long long)batch * nw < WF_TILED_SOLO_WAVES && rows(nw * 2) >= WF_TILED_MIN_ROWS) nw *= 2;
+    return rows(nw);
+}
+
 // wf_step_tiled can write the observation itself when the (x, y-run) blocks of obs are 4-byte aligned
 bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 
-// one workgroup of wf_step_tiled covers an environment of this shape: the step is that kernel's SOLO form, one launch
-bool wf_tiled_solo(int H, int W) { return tiled_shape(H, W).gx == 1; }
-
+// solo_rows > 0 (wf_tiled_solo_rows): one workgroup of wf_step_tiled, strips of that many rows, covers an environment
+// and the step is that kernel's SOLO form, one launch
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env,
-                              bool solo)
+                              int solo_rows)
 {
-    if (fam == WF_FAM_TILED && solo) {
-        const TiledShape ts = tiled_shape(a.H, a.W);
+    if (fam == WF_FAM_TILED && solo_rows > 0) {
+        const TiledShape ts = tiled_shape(a.H, a.W, solo_rows);
+        if (ts.gx != 1) return hipErrorInvalidValue;
         const bool containment = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
         const size_t collect_lds = containment ? (size_t)ts.nw * TR * COLLECT_WORDS * 8 : 0;
         const size_t flood_lds = containment ? ((size_t)a.H * (4 / ts.P) + (size_t)a.H * 4) * 8 : 0;
         const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * a.W * 3 + 16 : 0;
         const size_t lds = collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
         const dim3 grid((unsigned)a.batch), block(64u * (unsigned)ts.nw);
-#define WF_SOLO_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr)
+#define WF_SOLO_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr, (uint32_t)ts.tr)
         if (a.obs) { if (ts.P == 4) WF_SOLO_LAUNCH(true, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(true, 2); else WF_SOLO_LAUNCH(true, 1); }
         else { if (ts.P == 4) WF_SOLO_LAUNCH(false, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(false, 2); else WF_SOLO_LAUNCH(false, 1); }
 #undef WF_SOLO_LAUNCH
@@ -746,7 +774,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         (void)auto_seed;       // == cold->p.seed: finished environments are reset by the tick kernel itself
         const dim3 grid(gx * (unsigned)a.batch), block(64u * (unsigned)ts.nw);
         const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * a.W * 3 + 16 : 0;      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
-#define WF_TILED_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, false>), grid, block, obs_lds, s, a, mode, acc, (const u64 *)halo)
+#define WF_TILED_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, false>), grid, block, obs_lds, s, a, mode, acc, (const u64 *)halo, (uint32_t)TR)
         if (a.obs) { if (ts.P == 4) WF_TILED_LAUNCH(true, 4); else if (ts.P == 2) WF_TILED_LAUNCH(true, 2); else WF_TILED_LAUNCH(true, 1); }
         else { if (ts.P == 4) WF_TILED_LAUNCH(false, 4); else if (ts.P == 2) WF_TILED_LAUNCH(false, 2); else WF_TILED_LAUNCH(false, 1); }
 #undef WF_TILED_LAUNCH
