@@ -308,9 +308,11 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               # the tiled kernels covered there (marked by B + 10000); packed strips: 4 per wave up to W = 64, 2 up to 128
               (24, 24, 10096), (32, 20, 10064), (48, 48, 24), (64, 100, 12), (128, 128, 6), (36, 30, 40),
               (64, 300, 6), (128, 200, 4), (100, 140, 4),          # packed strips AND several workgroups per environment
-              # grids ONE tiled workgroup covers step in one launch (wf_step_tiled<solo>: every tiled shape above but
-              # 256x70, 256x256 and the last three); WF_NO_SOLO=1 keeps the two-launch form covered there (B + 20000)
-              (64, 64, 20024), (128, 128, 20006), (64, 100, 20012), (32, 20, 30064)]
+              # the tiled family's step is ONE launch (wf_step_tiled<solo>: a workgroup of up to 16 waves per environment)
+              # unless the observation is asked for and its tile does not fit a launch's LDS (256x256 here: every second
+              # step below goes without); WF_NO_SOLO=1 keeps the two-launch form covered everywhere (B + 20000)
+              (64, 64, 20024), (128, 128, 20006), (64, 100, 20012), (32, 20, 30064), (64, 300, 20006), (100, 140, 20004),
+              (256, 256, 20003)]
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)
@@ -351,8 +353,7 @@ def _run_big_grid(wf, monkeypatch, W, H, B):
         legacy = "WF_CELLS_LEGACY" in __import__("os").environ or (W * H > 1024 and B < 512)
         assert env.step_kernel == ("wf_step_cells" if legacy else "wf_step_env")
     if "tiled" in env.kernel_name:
-        solo = not no_solo and (W, H) not in ((256, 70), (256, 256), (64, 300), (128, 200), (100, 140))
-        assert env.step_kernel == ("wf_step_tiled<solo>" if solo else "wf_step_tiled"), env.step_kernel
+        assert env.step_kernel == ("wf_step_tiled" if no_solo else "wf_step_tiled<solo>"), env.step_kernel
     assert env.containment                                       # both big-grid families test containment
     env.reset(seed=123)
     op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=15000, containment=int(env.containment))
@@ -364,7 +365,11 @@ def _run_big_grid(wf, monkeypatch, W, H, B):
     rng = np.random.default_rng(W * 1000 + H)
     for t in range(T):
         a = rng.integers(0, 6, size=B).astype(np.int8)
-        obs, r, d, _ = env.step(a)
+        if t % 2 and H * W * 3 > 48 * 1024:  # a step without the observation: one launch whatever the grid's size
+            r, d = (x[0] for x in env.step_many(a))
+            obs = env.get_state()
+        else:
+            obs, r, d, _ = env.step(a)
         stopped = (envs["flags"] & O.F_RUNNING) == 0
         ro, do = O.step(planes, envs, a, op)
         if auto and stopped.any():         # auto-reset shapes
@@ -1142,10 +1147,14 @@ def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
 
 def test_config4_1024x256x256_full_size(wf, monkeypatch):
     """BASELINE configs[3] at its stated size: 1 024 batched 256x256 grids, ~1 % of the cells pre-ignited, fuel
-    U{10..40}.  The job takes the default split of the in-place tiled kernel (wf_tiled_prologue -> wf_step_tiled on three
-    shares of the batch, on three streams); a WF_NO_SPLIT twin must agree bit for bit on every plane, a strided sample of 32
-    environments (all shares, the seams and the last env) is replayed by the oracle, and the monotonicity laws
-    of the rule are checked on ALL cells.  30 no-op ticks (the configuration), then 12 steps with agents digging."""
+    U{10..40}, as bench.py runs it: through the asynchronous device API the job is three shares of the batch on three
+    streams, each one launch per step of the in-place tiled kernel (wf_step_tiled<solo>: a 16-wave workgroup per
+    environment).  A WF_NO_SPLIT twin stepped through the host API WITH the observation (whose tile does not fit a launch's
+    LDS at this size: wf_tiled_prologue -> wf_step_tiled, several workgroups per environment) must agree bit for bit on
+    every plane, a strided sample of 32 environments (all shares, the seams and the last env) is replayed by the oracle,
+    and the monotonicity laws of the rule are checked on ALL cells.  30 no-op ticks (the configuration), then 12 steps
+    with agents digging."""
+    import torch
     B, S = 1024, 256
     kw = dict(size=S, seed=44, fuel_range=(10, 40), ignite_ppm=10000, containment=True)
     monkeypatch.delenv("WF_NO_SPLIT", raising=False)
@@ -1153,7 +1162,10 @@ def test_config4_1024x256x256_full_size(wf, monkeypatch):
     monkeypatch.setenv("WF_NO_SPLIT", "1")
     b_env = wf.BatchedForestFire(B, **kw)
     monkeypatch.delenv("WF_NO_SPLIT", raising=False)
-    assert a_env.step_launches == 3 and b_env.step_launches == 1 and a_env.step_kernel == "wf_step_tiled"
+    assert a_env.step_launches == 3 and b_env.step_launches == 1 and a_env.step_kernel == "wf_step_tiled<solo>"
+    dev = torch.device("cuda", 0)
+    d_r = torch.empty((1, B), dtype=torch.float64, device=dev)
+    d_d = torch.empty((1, B), dtype=torch.uint8, device=dev)
     a_env.reset(seed=44)
     b_env.reset(seed=44)
     idx = np.unique(np.concatenate([np.arange(0, B, 37), [510, 511, 512, 513, B - 1]]))
@@ -1171,8 +1183,12 @@ def test_config4_1024x256x256_full_size(wf, monkeypatch):
     prev = p0
     for t in range(42):
         a = None if t < 30 else rng.integers(0, 5, size=B).astype(np.int8)
-        _, ra, da, _ = a_env.step(a)
-        _, rb, db, _ = b_env.step(a)
+        d_a = None if a is None else torch.from_numpy(a).to(dev)
+        torch.cuda.synchronize()
+        a_env.step_device(d_a, 1, d_r, d_d, update_mask=1)
+        a_env.sync()
+        ra, da = d_r.cpu().numpy()[0], d_d.cpu().numpy()[0].astype(bool)
+        obs_b, rb, db, _ = b_env.step(a)
         np.testing.assert_array_equal(ra, rb, err_msg=f"split vs single: reward t={t}")
         np.testing.assert_array_equal(da, db, err_msg=f"split vs single: done t={t}")
         ro, do = O.step(sp, se, None if a is None else a[idx], op)
@@ -1190,6 +1206,7 @@ def test_config4_1024x256x256_full_size(wf, monkeypatch):
             assert (p[..., 3].reshape(B, -1).sum(axis=1) <= 1).all()
             prev = p
     pb, eb = b_env.download()
+    np.testing.assert_array_equal(obs_b[idx], O.get_state(sp), err_msg="observation of the last step")
     np.testing.assert_array_equal(prev, pb, err_msg="split vs single launch: planes")
     np.testing.assert_array_equal(e, eb, err_msg="split vs single launch: records")
     assert (prev[..., 0] == 1).mean() > 0.02                      # the fronts have spread
@@ -1859,7 +1876,7 @@ def test_bench_contract_single_and_two_ranks(wf):
     assert "custom size" in d1["config"]["workload"] and "configs[2]" not in d1["config"]["workload"]
     for leg, tag in (("c2", "configs[1]"), ("c4", "configs[3]")):
         assert tag in d1["configs"][leg]["workload"] and 0 < d1["configs"][leg]["roofline"]["frac"] < 1.2, d1["configs"][leg]
-    assert d1["configs"]["c4"]["roofline"]["kernel"] == "wf_step_tiled"
+    assert d1["configs"]["c4"]["roofline"]["kernel"] == "wf_step_tiled<solo>"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.pop("WORLD_SIZE", None)
     if torch.cuda.device_count() < 2:

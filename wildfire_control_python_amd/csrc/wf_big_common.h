@@ -97,6 +97,19 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
     const uint32_t qa = ay * W + ax;
     uint32_t qd = inb ? ny * W + nx : qa;
     const uint32_t td = pe[(size_t)qd * 4], tcur = pe[(size_t)qa * 4];
+    // the eight cells around the one a dig would take (it is `qd` whatever the action turns out to do), for the test
+    // below: requested WITH the two cells above, not after them - this runs on one lane with a workgroup waiting for it
+    const bool ring_test = (a.hot_flags & WF_HOT_CONTAINMENT) && !(fl & (WF_F_BORDER | WF_F_CONTAINED)) && (fl & WF_F_REACH_VALID);
+    const int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
+    uint32_t ring_ty[8];
+    if (ring_test) {
+        const uint32_t xd = qd % W, yd = qd / W;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
+            ring_ty[r] = rx < W && ry < H ? (uint32_t)pe[(size_t)(ry * W + rx) * 4] : 0xffu;
+        }
+    }
     const uint32_t moved = inb & (td != WF_WATER ? 1u : 0u);                          // :146 traversable
     const uint32_t dfire = moved & (FIRE_SET >> td) & 1u;                             // is_burning(): fire, blocked fire
     uint32_t dug = moved & ((fl >> 2) & 1u) & (DIG_SET >> td) & 1u;                   // :151-152, :125-133
@@ -127,11 +140,11 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
             const uint32_t xd = qd % W, yd = qd / W;
             uint32_t ring = 0, bn = 0;
             bool zn = false;
-            const int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
+#pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
                 if (rx < W && ry < H) {
-                    const uint32_t ty = pe[(size_t)(ry * W + rx) * 4];
+                    const uint32_t ty = ring_ty[r];
                     if (ty < WF_DIRT) ring |= 1u << r;
                     if (blocked_burning(ty) && !(r & 1)) zn = true;        // burning dirt / blocked fire hangs on the board through its neighbours
                     if (!(r & 1) && (rx == 0 || ry == 0 || rx == W - 1 || ry == H - 1)) bn |= 1u << r;

@@ -137,6 +137,8 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
                               int solo_rows);
 // rows per strip of the tiled family's one-launch step of this shape (0: the shape needs several workgroups per environment)
 int wf_tiled_solo_rows(int H, int W, int want, int batch);
+bool wf_tiled_solo_fits(int H, int W, int rows, bool containment, bool obs);   // ... and such a launch's LDS fits (else: the two-launch form)
+#define WF_SOLO_MAX_WAVES 16          // waves of a SOLO workgroup
 #define WF_TILED_MIN_ROWS 8           // ... never shorter than this for the sake of more waves
 #define WF_TILED_SOLO_WAVES 8192      // ... which a job with fewer waves than this (8 per SIMD) gets
 #define WF_RIVER_MAX_H 2048       // big-grid families: rows of a grid whose river fits the reset kernel's LDS row table

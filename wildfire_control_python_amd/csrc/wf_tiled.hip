@@ -221,15 +221,15 @@ __device__ __forceinline__ void tiled_row(uint32_t r, uint32_t H, uint32_t LW, u
 
 template <bool STEP, int REACH, bool OBS, int P>
 __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H, uint32_t LW, uint32_t ign, const Pack<P> &pk,
-                                            const uint4 *src, const TiledDst &dst, const ObsTile &ot, const uint4 &first, const u64 (&Sf)[4],
-                                            const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, u64 *collect, TiledAcc &A)
+                                            const uint4 *src, const TiledDst &dst, const ObsTile &ot, const uint4 &first, const uint4 &second,
+                                            const u64 (&Sf)[4], const u64 (&Sabove)[4], const u64 (&Sbelow)[4], const u64 *reach_e, u64 *collect,
+                                            TiledAcc &A)
 {
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
-    uint4 C[3] = { first, inert, inert };
+    uint4 C[3] = { first, second, inert };
     u64 M[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { M[0][j] = Sf[j]; M[2][j] = Sabove[j]; M[1][j] = 0; }
-    if (r0 + 1 < r1 && pk.col_ok && r0 + 1u + pk.row_off < H) C[1] = src[(r0 + 1u) * LW];
     for (uint32_t r = r0; r < r1; r += 3u) {
         static_for<3>([&](auto K) {
             constexpr int k = decltype(K)::value, kn = (k + 1) % 3, kp = (k + 2) % 3;
@@ -326,12 +326,13 @@ __device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e
 // not a launch), World.RUNNING / reward / done from reductions in LDS: one launch per step, nothing but the cells, the
 // record and the board touched in memory.
 template <bool OBS, int P, bool SOLO>
-__global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer, const uint32_t tr)
+__global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer, const uint32_t tr)
 {
-    __shared__ u64 halo[4][2][4];                    // [wave][first,last row of each of its segments][component]
-    __shared__ uint16_t river_tab[4][64];            // auto-reset with rivers: water column of each of a wave's rows
+    constexpr int MAXW = SOLO ? WF_SOLO_MAX_WAVES : 4;  // waves per workgroup (SOLO: as many as it takes to cover the grid)
+    __shared__ u64 halo[MAXW][2][4];                 // [wave][first,last row of each of its segments][component]
+    __shared__ uint16_t river_tab[MAXW][64];         // auto-reset with rivers: water column of each of a wave's rows
     __shared__ uint4 s_ev;                           // SOLO: the environment's record between big_pre_env and big_post_env
-    __shared__ uint32_t s_word[2], s_red[4][2];      // SOLO: step mode, the flood's "changed"; per wave: result bits, healthy cells
+    __shared__ uint32_t s_word[2], s_red[MAXW][2];   // SOLO: step mode, the flood's "changed"; per wave: result bits, healthy cells
     // [SOLO with the containment test: the sweep's collected masks, nw * 16 * COLLECT_WORDS words]
     // [OBS: [rows of the workgroup][W*3] (+4) staging tile | solo_flood's area, once the tile has been flushed]
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -431,11 +432,13 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
 
     // ---- prologue: masks of every segment's first and last row (original state) -> LDS
-    uint4 first = inert, last = inert;
+    uint4 first = inert, last = inert, second = inert;
     u64 Sf[4] = { 0, 0, 0, 0 }, Sl[4] = { 0, 0, 0, 0 };
     if (has_rows) {
         if (pk.col_ok && r0 + pk.row_off < H) first = src[r0 * LW];
         if (pk.col_ok && r1 - 1u + pk.row_off < H) last = src[(r1 - 1u) * LW];
+        // (the sweep's second row, requested here: it arrives while the halos are exchanged)
+        if (r0 + 1 < r1 && pk.col_ok && r0 + 1u + pk.row_off < H) second = src[(r0 + 1u) * LW];
         still_masks(first, Sf);
         still_masks(last, Sl);
     }
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256) void wf_step_tiled(const WfArgs a, const uint8
     // ---- sweep
     u64 *const collect_w = collect + wv * (uint32_t)(TR * COLLECT_WORDS);
     auto sweep = [&](auto ST, auto RM) {
-        tiled_sweep<decltype(ST)::value, decltype(RM)::value, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, Sf, Sp, Sb, reach_e, collect_w, A);
+        tiled_sweep<decltype(ST)::value, decltype(RM)::value, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, second, Sf, Sp, Sb, reach_e, collect_w, A);
     };
     typedef std::integral_constant<int, REACH_NONE> RNone;
     typedef std::integral_constant<int, REACH_TEST> RTest;
@@ -706,7 +709,7 @@ extern "C" __attribute__((visibility("default"))) void wf_debug_read(unsigned lo
 
 // Shape of a wf_step_tiled launch: strips packed side by side per wave, waves per workgroup, workgroups per environment
 struct TiledShape { int P, nw, rows_per_wg, gx, tr; };
-static TiledShape tiled_shape(int H, int W, int tr = TR)
+static TiledShape tiled_shape(int H, int W, int tr = TR, int max_waves = 4)
 {
     TiledShape t;
     const int LW = W / 4;
@@ -714,29 +717,44 @@ static TiledShape tiled_shape(int H, int W, int tr = TR)
     t.tr = tr;
     const int rows_per_wave = t.P * tr;
     t.nw = (H + rows_per_wave - 1) / rows_per_wave;
-    if (t.nw > 4) t.nw = 4;
+    if (t.nw > max_waves) t.nw = max_waves;
     t.rows_per_wg = t.nw * rows_per_wave;
     t.gx = (H + t.rows_per_wg - 1) / t.rows_per_wg;
     return t;
 }
 int wf_tiled_groups(int H, int W) { return tiled_shape(H, W).gx; }
 
-// Rows per strip of the one-launch (SOLO) step of `batch` H x W grids, 0 if one workgroup of TR-row strips does not
-// cover such a grid.  The strips are as short as the workgroup's waves allow (a 32x32 grid: four strips of 8 rows side by
-// side in ONE wave - 8 sweep positions, every lane busy - not two of 16; 48x48: four of 12), and a job too small to
-// give every SIMD a few waves takes twice the waves at half the strip (4 096 x 64x64: 24.3 instead of 29.9 us per step;
-// a sweep is serial, so with one or two waves per SIMD it is their latency that shows) - but only then: a wave's
-// fixed part (halo rows, barriers) is worth about five rows (16 384 x 64x64: 83 us per step with 16-row strips, 102
-// with 8).  `want` > 0: the caller's choice (WF_TILED_ROWS), honoured if four waves of such strips cover the grid.
+// Rows per strip of the one-launch (SOLO) step of `batch` H x W grids: its workgroup has as many waves as it takes to
+// cover the grid (up to WF_SOLO_MAX_WAVES: 16 waves of one 16-row strip for 256x256), 0 if that many do not.  The strips
+// are as short as the waves allow (a 32x32 grid: four strips of 8 rows side by side in ONE wave - 8 sweep positions,
+// every lane busy - not two of 16; 48x48: four of 12), and a job too small to give every SIMD a few waves takes twice
+// the waves at half the strip (4 096 x 64x64: 24.3 instead of 29.9 us per step; a sweep is serial, so with one or two
+// waves per SIMD it is their latency that shows) - but only then: a wave's fixed part (halo rows, barriers) is worth
+// about five rows (16 384 x 64x64: 83 us per step with 16-row strips, 102 with 8).  `want` > 0: the caller's choice
+// (WF_TILED_ROWS), honoured if a workgroup of such strips covers the grid.
 int wf_tiled_solo_rows(int H, int W, int want, int batch)
 {
-    const TiledShape t = tiled_shape(H, W);
+    const TiledShape t = tiled_shape(H, W, TR, WF_SOLO_MAX_WAVES);
     if (t.gx != 1) return 0;
-    if (want > 0 && want <= TR && tiled_shape(H, W, want).gx == 1) return want;
+    if (want > 0 && want <= TR && tiled_shape(H, W, want, WF_SOLO_MAX_WAVES).gx == 1) return want;
     int nw = t.nw;
     auto rows = [&](int n) { return (H + t.P * n - 1) / (t.P * n); };
-    while (nw * 2 <= 4 && (long long)batch * nw < WF_TILED_SOLO_WAVES && rows(nw * 2) >= WF_TILED_MIN_ROWS) nw *= 2;
+    while (nw * 2 <= WF_SOLO_MAX_WAVES && (long long)batch * nw < WF_TILED_SOLO_WAVES && rows(nw * 2) >= WF_TILED_MIN_ROWS) nw *= 2;
     return rows(nw);
+}
+
+// dynamic LDS of a SOLO launch; it is one while this fits the 64 KiB a launch gets without asking (a 256x256 grid's
+// observation tile does not: such a step takes the two-launch form)
+static size_t solo_lds(const TiledShape &ts, int H, int W, bool containment, bool obs)
+{
+    const size_t collect_lds = containment ? (size_t)ts.nw * TR * COLLECT_WORDS * 8 : 0;
+    const size_t flood_lds = containment ? ((size_t)H * (4 / ts.P) + (size_t)H * 4) * 8 : 0;
+    const size_t obs_lds = obs ? (size_t)ts.rows_per_wg * W * 3 + 16 : 0;
+    return collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
+}
+bool wf_tiled_solo_fits(int H, int W, int rows, bool containment, bool obs)
+{
+    return rows > 0 && solo_lds(tiled_shape(H, W, rows, WF_SOLO_MAX_WAVES), H, W, containment, obs) <= 64 * 1024 - 4096;
 }
 
 // wf_step_tiled can write the observation itself when the (x, y-run) blocks of obs are 4-byte aligned
@@ -747,14 +765,11 @@ bool wf_tiled_fused_obs(int H, int W) { return H % 4 == 0 && W <= 256; }
 hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint32_t *acc, u64 *halo, u64 auto_seed, hipStream_t s, bool per_env,
                               int solo_rows)
 {
-    if (fam == WF_FAM_TILED && solo_rows > 0) {
-        const TiledShape ts = tiled_shape(a.H, a.W, solo_rows);
+    const bool containment = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
+    if (fam == WF_FAM_TILED && wf_tiled_solo_fits(a.H, a.W, solo_rows, containment, a.obs != nullptr)) {
+        const TiledShape ts = tiled_shape(a.H, a.W, solo_rows, WF_SOLO_MAX_WAVES);
         if (ts.gx != 1) return hipErrorInvalidValue;
-        const bool containment = (a.hot_flags & WF_HOT_CONTAINMENT) != 0;
-        const size_t collect_lds = containment ? (size_t)ts.nw * TR * COLLECT_WORDS * 8 : 0;
-        const size_t flood_lds = containment ? ((size_t)a.H * (4 / ts.P) + (size_t)a.H * 4) * 8 : 0;
-        const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * a.W * 3 + 16 : 0;
-        const size_t lds = collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
+        const size_t lds = solo_lds(ts, a.H, a.W, containment, a.obs != nullptr);
         const dim3 grid((unsigned)a.batch), block(64u * (unsigned)ts.nw);
 #define WF_SOLO_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr, (uint32_t)ts.tr)
         if (a.obs) { if (ts.P == 4) WF_SOLO_LAUNCH(true, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(true, 2); else WF_SOLO_LAUNCH(true, 1); }
