@@ -310,7 +310,8 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               (64, 300, 6), (128, 200, 4), (100, 140, 4),          # packed strips AND several workgroups per environment
               # the tiled family's step is ONE launch (wf_step_tiled<solo>: a workgroup of up to 16 waves per environment)
               # unless the observation is asked for and its tile does not fit a launch's LDS (256x256 here: every second
-              # step below goes without); WF_NO_SOLO=1 keeps the two-launch form covered everywhere (B + 20000)
+              # step below goes without) or the job has thousands of waves in workgroups of more than four (not here);
+              # WF_NO_SOLO=1 keeps the two-launch form covered everywhere (B + 20000)
               (64, 64, 20024), (128, 128, 20006), (64, 100, 20012), (32, 20, 30064), (64, 300, 20006), (100, 140, 20004),
               (256, 256, 20003)]
 
@@ -1148,9 +1149,9 @@ def test_config2_4096x10x10_noop_16_ticks_per_call(wf):
 def test_config4_1024x256x256_full_size(wf, monkeypatch):
     """BASELINE configs[3] at its stated size: 1 024 batched 256x256 grids, ~1 % of the cells pre-ignited, fuel
     U{10..40}, as bench.py runs it: through the asynchronous device API the job is three shares of the batch on three
-    streams, each one launch per step of the in-place tiled kernel (wf_step_tiled<solo>: a 16-wave workgroup per
-    environment).  A WF_NO_SPLIT twin stepped through the host API WITH the observation (whose tile does not fit a launch's
-    LDS at this size: wf_tiled_prologue -> wf_step_tiled, several workgroups per environment) must agree bit for bit on
+    streams, each wf_tiled_prologue -> wf_step_tiled per step (a job of this many 256x256 grids keeps the four-wave
+    workgroups, four per environment; fewer such grids step in one launch of 16-wave workgroups: the big-grid shape
+    table above).  A WF_NO_SPLIT twin stepped through the host API with the observation must agree bit for bit on
     every plane, a strided sample of 32 environments (all shares, the seams and the last env) is replayed by the oracle,
     and the monotonicity laws of the rule are checked on ALL cells.  30 no-op ticks (the configuration), then 12 steps
     with agents digging."""
@@ -1162,7 +1163,7 @@ def test_config4_1024x256x256_full_size(wf, monkeypatch):
     monkeypatch.setenv("WF_NO_SPLIT", "1")
     b_env = wf.BatchedForestFire(B, **kw)
     monkeypatch.delenv("WF_NO_SPLIT", raising=False)
-    assert a_env.step_launches == 3 and b_env.step_launches == 1 and a_env.step_kernel == "wf_step_tiled<solo>"
+    assert a_env.step_launches == 3 and b_env.step_launches == 1 and a_env.step_kernel == "wf_step_tiled"
     dev = torch.device("cuda", 0)
     d_r = torch.empty((1, B), dtype=torch.float64, device=dev)
     d_d = torch.empty((1, B), dtype=torch.uint8, device=dev)
@@ -1876,7 +1877,7 @@ def test_bench_contract_single_and_two_ranks(wf):
     assert "custom size" in d1["config"]["workload"] and "configs[2]" not in d1["config"]["workload"]
     for leg, tag in (("c2", "configs[1]"), ("c4", "configs[3]")):
         assert tag in d1["configs"][leg]["workload"] and 0 < d1["configs"][leg]["roofline"]["frac"] < 1.2, d1["configs"][leg]
-    assert d1["configs"]["c4"]["roofline"]["kernel"] == "wf_step_tiled<solo>"
+    assert d1["configs"]["c4"]["roofline"]["kernel"] == "wf_step_tiled"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.pop("WORLD_SIZE", None)
     if torch.cuda.device_count() < 2:

@@ -730,13 +730,18 @@ int wf_tiled_groups(int H, int W) { return tiled_shape(H, W).gx; }
 // every lane busy - not two of 16; 48x48: four of 12), and a job too small to give every SIMD a few waves takes twice
 // the waves at half the strip (4 096 x 64x64: 24.3 instead of 29.9 us per step; a sweep is serial, so with one or two
 // waves per SIMD it is their latency that shows) - but only then: a wave's fixed part (halo rows, barriers) is worth
-// about five rows (16 384 x 64x64: 83 us per step with 16-row strips, 102 with 8).  `want` > 0: the caller's choice
-// (WF_TILED_ROWS), honoured if a workgroup of such strips covers the grid.
+// about five rows (16 384 x 64x64: 83 us per step with 16-row strips, 102 with 8).  The same count decides whether a
+// grid that needs MORE than four waves is stepped this way at all: a 16-wave workgroup starts and ends as one - its
+// waves wait for the first thread's agent logic and for the slowest strip - which a job with enough waves to fill the
+// chip pays for (1 024 x 256x256, no-op actions: 93.5 us per step against 82.1 in the two-launch form whose workgroups
+// are four waves; 256 x 256x256: 32 against 54).  `want` > 0: the caller's choice (WF_TILED_ROWS), honoured if a
+// workgroup of such strips covers the grid.
 int wf_tiled_solo_rows(int H, int W, int want, int batch)
 {
     const TiledShape t = tiled_shape(H, W, TR, WF_SOLO_MAX_WAVES);
     if (t.gx != 1) return 0;
     if (want > 0 && want <= TR && tiled_shape(H, W, want, WF_SOLO_MAX_WAVES).gx == 1) return want;
+    if (t.nw > 4 && (long long)batch * t.nw >= WF_TILED_SOLO_WAVES) return 0;
     int nw = t.nw;
     auto rows = [&](int n) { return (H + t.P * n - 1) / (t.P * n); };
     while (nw * 2 <= WF_SOLO_MAX_WAVES && (long long)batch * nw < WF_TILED_SOLO_WAVES && rows(nw * 2) >= WF_TILED_MIN_ROWS) nw *= 2;
