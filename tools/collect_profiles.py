@@ -27,6 +27,8 @@ RUNS = [  # (directory, what was run)
                       "   (1 048 576 x 14x14 = 822 MB of state: true HBM streaming, one launch per step)"),
     ("kt_c2", "python3 bench.py --no-cpu-baseline --legs c2 --steps 100 --warmup 10 --fused 0   (the wf_step_ticks rows: BASELINE configs[1], "
               "4 096 x 10x10, no-op, one launch = 16 ticks; the other rows are the headline loop of the same run)"),
+    ("kt_mid", "WF_NO_SPLIT=1 python3 bench.py --no-cpu-baseline --legs mid_64 --steps 100 --warmup 10 --fused 0   (the wf_step_tiled rows: 4 096 x 64x64, "
+               "one launch = the whole step - agent logic, tick, flood, reward; the other rows are the headline loop of the same run)"),
 ]
 
 
@@ -65,7 +67,7 @@ for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; 
                         ("c2", "wf_step_ticks", "4 096 x 10x10, no-op, 16 ticks per call (1.6 MB; the c2 leg of a bench run under WF_NO_SPLIT=1: ONE launch per call; "
                                                "un-profiled a call is four part launches on the context's streams)"),
                         ("wind", "wf_step_group", "65 536 x 14x14, wind 'random' (51 MB of planes + 51 MB of heat counts; the c3_wind leg of a bench run under WF_NO_SPLIT=1: one launch per step)"),
-                        ("mid", "wf_step_tiled", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch sequence per step; wf_step_tiled only)")):
+                        ("mid", "wf_step_tiled", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch per step - wf_step_tiled<.., SOLO> is the whole step: agent logic, tick, flood, reward)")):
     lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
     for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
         if not os.path.isdir(d):
@@ -121,7 +123,7 @@ t["other_sizes"]["c2"] = traffic("c2", "wf_step_ticks<10,10,false>", 4096 * 100,
                                  "stays in registers between the ticks, so a launch moves the state once: compare with state_bytes, not with the 16 ticks' algorithmic bytes")
 t["other_sizes"]["c2"]["algorithmic_bytes_per_launch"] = 4096 * 100 * 8 * 16
 t["other_sizes"]["c3_wind"] = traffic("wind", "wf_step_group<14,14,wind>", 65536 * 196, "65536 x 14x14, wind 'random' (planes + per-direction heat counts), bench inputs")
-t["other_sizes"]["mid_64"] = traffic("mid", "wf_step_tiled", 4096 * 4096, "4096 x 64x64, bench inputs (67 MB; wf_step_tiled only: the prologue's traffic is not in it)")
+t["other_sizes"]["mid_64"] = traffic("mid", "wf_step_tiled", 4096 * 4096, "4096 x 64x64, bench inputs (67 MB; one launch = the whole step of its environments)")
 # what bench.py looks up, per leg of its JSON line; every entry names the PMC pass it came from
 t["kernel_source_sha256"] = open(f"{src}/kernel_source_sha256.txt").read().strip()
 t["legs"] = {}

@@ -15,7 +15,7 @@ HB="--batch 1048576 --steps 120 --warmup 20"
 C5="--batch 125000 --steps 400 --warmup 40"
 C2="python3 bench.py --no-cpu-baseline --legs c2 --steps 100 --warmup 10 --fused 0"    # (the headline loop runs too; the wf_step_ticks rows are the leg's)
 WIND="python3 bench.py --no-cpu-baseline --legs c3_wind --steps 100 --warmup 10 --fused 0"   # (wf_step_group<..,WIND> rows: the leg)
-MID="python3 bench.py --no-cpu-baseline --legs mid_64 --steps 100 --warmup 10 --fused 0"     # (wf_step_tiled / wf_tiled_prologue rows: the leg)
+MID="python3 bench.py --no-cpu-baseline --legs mid_64 --steps 100 --warmup 10 --fused 0"     # (wf_step_tiled<.., SOLO> rows: the leg)
 python3 -c "import bench; print(bench.kernel_source_sha256())" > $out/kernel_source_sha256.txt
 PM="--steps 40 --warmup 400"
 # ---- kernel-trace stats
@@ -29,6 +29,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c4 -- $B $C4 > $
 WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c4_single -- $B $C4 > $out/kt_c4_single.log 2>&1
 WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_hbm_single -- $B $HB > $out/kt_hbm_single.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -- $C2 > $out/kt_c2.log 2>&1
+WF_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_mid -- $MID > $out/kt_mid.log 2>&1
 # ---- counters (one launch per step: kernels serialise under --pmc anyway)
 export WF_NO_SPLIT=1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -54,6 +55,6 @@ done
 python3 tools/c4_write_amp.py > $out/c4_write_amp.json 2> $out/c4_write_amp.err
 # ---- the same bench un-profiled, for the agreement check
 python3 bench.py > $out/bench_plain.json 2> $out/bench_plain.err
-for d in kt_c3 kt_c3_single kt_c3_split kt_c5 kt_c4 kt_c4_single kt_hbm_single kt_c2; do echo "== $d"; find $out/$d -name "*kernel_stats.csv" | head -1 | xargs cat | grep -E "Name|wf_"; done
+for d in kt_c3 kt_c3_single kt_c3_split kt_c5 kt_c4 kt_c4_single kt_hbm_single kt_c2 kt_mid; do echo "== $d"; find $out/$d -name "*kernel_stats.csv" | head -1 | xargs cat | grep -E "Name|wf_"; done
 for d in $out/pmc_*; do [ -d $d ] && { echo "== $d"; python tools/pmc_summary.py $d 1 | grep -A12 "wf_"; }; done
 tail -c 600 $out/bench_plain.json
