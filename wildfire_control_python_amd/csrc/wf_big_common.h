@@ -102,8 +102,8 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
     const bool ring_test = (a.hot_flags & WF_HOT_CONTAINMENT) && !(fl & (WF_F_BORDER | WF_F_CONTAINED)) && (fl & WF_F_REACH_VALID);
     const int DX[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, DY[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
     uint32_t ring_ty[8];
+    const uint32_t xd = inb ? nx : ax, yd = inb ? ny : ay;        // (x, y) of qd
     if (ring_test) {
-        const uint32_t xd = qd % W, yd = qd / W;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const uint32_t rx = xd + (uint32_t)DX[r], ry = yd + (uint32_t)DY[r];
@@ -137,7 +137,6 @@ __device__ __forceinline__ uint32_t big_pre_env(const WfArgs &a, const uint32_t 
         m |= MODE_PRECHECK;
         bool flood = !(fl & WF_F_REACH_VALID);
         if (dug && !flood) {
-            const uint32_t xd = qd % W, yd = qd / W;
             uint32_t ring = 0, bn = 0;
             bool zn = false;
 #pragma unroll

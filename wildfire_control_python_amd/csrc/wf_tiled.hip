@@ -341,7 +341,7 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
     const uint32_t lane = __lane_id();
     const uint32_t wv = rfl(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
-    const uint32_t gx = (H + nw * WR - 1u) / (nw * WR);          // workgroups per environment
+    const uint32_t gx = SOLO ? 1u : (H + nw * WR - 1u) / (nw * WR);     // workgroups per environment
     // (workgroups are dispatched in blockIdx order: a reversed step walks the batch from its far end)
     const uint32_t bid = a.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
     const uint32_t e = bid / gx;
