@@ -622,9 +622,10 @@ WfFamily wf_pick_family(int H, int W)
 #define X(w, h) if (W == w && H == h) return WF_FAM_WAVE;
     WF_WAVE_SHAPES(X)
 #undef X
-    // the tiled family costs a 256-thread prologue workgroup per environment and sweeps at most 4 x 16 rows per wave:
-    // below 32x32 the generic family's wave-per-environment kernel is faster (us per 13 M cells: 20x20 68 against 204,
-    // 24x24 92 against 211; 32x32 123 against 111, 48x48 116 against 69, 64x64 182 against 54)
+    // a wave of the tiled family has a fixed part worth about five rows of sweep, and narrow grids leave lanes idle:
+    // below 28x28 the generic family's wave-per-environment kernel is faster (us per step, generic against the tiled
+    // family's one-launch step, round 4: 32 768 x 20x20 49 against 60, 32 768 x 24x24 61 against 66, 16 384 x 28x28 44
+    // against 37, 16 384 x 32x32 - against 39, 8 192 x 48x48 - against 30)
     if (W >= 4 && W <= 256 && W % 4 == 0 && H >= 1 && (long long)H * W > WF_TILED_MIN_CELLS) return WF_FAM_TILED;
     return WF_FAM_CELLS;
 }

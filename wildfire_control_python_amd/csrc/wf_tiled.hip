@@ -2,7 +2,9 @@
 //
 // Same rule as wf_kernels.hip (synchronous integer restatement of
 // Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step of the TILED family
-// (W % 4 == 0, W <= 256, at least 1 024 cells) is two launches:
+// (W % 4 == 0, W <= 256, at least 784 cells) is ONE launch of wf_step_tiled<.., SOLO> - a workgroup per environment
+// does what the two kernels below do between them, see there - or, for jobs of thousands of waves in workgroups
+// of more than four (1 024 x 256x256) and for observation tiles past a launch's LDS, two launches:
 //   wf_tiled_prologue   one workgroup per environment: Agent.move / toggle / death (environment.py:116-171) with
 //                       the dug cell and the agent_pos bytes written straight into the grid; the border-reachability
 //                       flood when a dig may have cut a region off (run fill on linear row bitmaps, relax_row_bitmaps);
