@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline loop only: no fused / observation / host-API / single-launch / config legs (profiling passes)")
-    ap.add_argument("--legs", default="c2,c2_n64,c4,c5_shard,hbm_1m,c3_wind,mid_64", help="extra config legs to run (comma separated)")
+    ap.add_argument("--legs", default="c2,c2_n64,c4,c5_shard,hbm_1m,c3_wind,mid_64,mid_128", help="extra config legs to run (comma separated)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--ignite-ppm", type=int, default=0, help="extra pre-ignited cells per million at reset (config 4)")
@@ -526,9 +526,11 @@ def main():
             "c5_shard": dict(S=14, B=125000, noop=False, env_id0=875000, steps=400, warmup=40),
             "hbm_1m": dict(S=14, B=1048576, noop=False, steps=120, warmup=20),
             # informational (no BASELINE config): the reference's off-by-default wind option at the headline size (the wave
-            # family's group-layout kernel with per-direction heat counts), and a mid-size grid (tiled family, four strips per wave)
+            # family's group-layout kernel with per-direction heat counts), and two mid-size grids (tiled family, one launch per step and
+            # part: a workgroup per environment - 64x64: two waves of four 8-row strips, 128x128: eight waves of two)
             "c3_wind": dict(S=14, B=65536, noop=False, steps=200, warmup=20, wind="random"),
             "mid_64": dict(S=64, B=4096, noop=False, steps=200, warmup=20),
+            "mid_128": dict(S=128, B=1024, noop=False, steps=200, warmup=20),
         }
         for nm in want:
             if nm in specs:

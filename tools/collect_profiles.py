@@ -67,7 +67,8 @@ for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; 
                         ("c2", "wf_step_ticks", "4 096 x 10x10, no-op, 16 ticks per call (1.6 MB; the c2 leg of a bench run under WF_NO_SPLIT=1: ONE launch per call; "
                                                "un-profiled a call is four part launches on the context's streams)"),
                         ("wind", "wf_step_group", "65 536 x 14x14, wind 'random' (51 MB of planes + 51 MB of heat counts; the c3_wind leg of a bench run under WF_NO_SPLIT=1: one launch per step)"),
-                        ("mid", "wf_step_tiled", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch per step - wf_step_tiled<.., SOLO> is the whole step: agent logic, tick, flood, reward)")):
+                        ("mid", "wf_step_tiled", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch per step - wf_step_tiled<.., SOLO> is the whole step: agent logic, tick, flood, reward)"),
+                        ("mid128", "wf_step_tiled", "1 024 x 128x128 (67 MB; the mid_128 leg of a bench run under WF_NO_SPLIT=1: one launch per step, eight-wave workgroups)")):
     lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
     for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
         if not os.path.isdir(d):
@@ -124,11 +125,12 @@ t["other_sizes"]["c2"] = traffic("c2", "wf_step_ticks<10,10,false>", 4096 * 100,
 t["other_sizes"]["c2"]["algorithmic_bytes_per_launch"] = 4096 * 100 * 8 * 16
 t["other_sizes"]["c3_wind"] = traffic("wind", "wf_step_group<14,14,wind>", 65536 * 196, "65536 x 14x14, wind 'random' (planes + per-direction heat counts), bench inputs")
 t["other_sizes"]["mid_64"] = traffic("mid", "wf_step_tiled", 4096 * 4096, "4096 x 64x64, bench inputs (67 MB; one launch = the whole step of its environments)")
+t["other_sizes"]["mid_128"] = traffic("mid128", "wf_step_tiled", 1024 * 16384, "1024 x 128x128, bench inputs (67 MB; one launch = the whole step of its environments)")
 # what bench.py looks up, per leg of its JSON line; every entry names the PMC pass it came from
 t["kernel_source_sha256"] = open(f"{src}/kernel_source_sha256.txt").read().strip()
 t["legs"] = {}
 for leg, key, cfg in (("c3", None, "c3parts"), ("c4", "c4_tiled", "c4"), ("hbm_1m", "hbm_1m", "hbm"), ("c5_shard", "c5_shard", "c5"), ("c2", "c2", "c2"),
-                      ("c3_wind", "c3_wind", "wind"), ("mid_64", "mid_64", "mid")):
+                      ("c3_wind", "c3_wind", "wind"), ("mid_64", "mid_64", "mid"), ("mid_128", "mid_128", "mid128")):
     e = dict(t if key is None else t["other_sizes"][key])
     for k in ("other_sizes", "legs", "note", "round", "kernel_source_sha256", "single_launch"):
         e.pop(k, None)

@@ -16,6 +16,7 @@ C5="--batch 125000 --steps 400 --warmup 40"
 C2="python3 bench.py --no-cpu-baseline --legs c2 --steps 100 --warmup 10 --fused 0"    # (the headline loop runs too; the wf_step_ticks rows are the leg's)
 WIND="python3 bench.py --no-cpu-baseline --legs c3_wind --steps 100 --warmup 10 --fused 0"   # (wf_step_group<..,WIND> rows: the leg)
 MID="python3 bench.py --no-cpu-baseline --legs mid_64 --steps 100 --warmup 10 --fused 0"     # (wf_step_tiled<.., SOLO> rows: the leg)
+MID128="python3 bench.py --no-cpu-baseline --legs mid_128 --steps 100 --warmup 10 --fused 0"
 python3 -c "import bench; print(bench.kernel_source_sha256())" > $out/kernel_source_sha256.txt
 PM="--steps 40 --warmup 400"
 # ---- kernel-trace stats
@@ -41,6 +42,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_c2_$c -- $C2 > $out/pmc_c2_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_wind_$c -- $WIND > $out/pmc_wind_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_mid_$c -- $MID > $out/pmc_mid_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_mid128_$c -- $MID128 > $out/pmc_mid128_$c.log 2>&1
 done
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_c3_l2 -- $B $PM > $out/pmc_c3_l2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_c3_insts -- $B $PM > $out/pmc_c3_insts.log 2>&1
