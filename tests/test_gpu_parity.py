@@ -463,13 +463,21 @@ def _circle_actions(ge, W, H, rng):
 
 
 @pytest.mark.parametrize("W,H,family", [(24, 24, "tiled"), (32, 20, "tiled"), (14, 14, None), (13, 13, None), (30, 23, None), (11, 14, None),
-                                        (24, 24, None), (60, 44, None), (51, 47, None)])
+                                        (24, 24, None), (60, 44, None), (51, 47, None),
+                                        # the tiled family by itself: one launch per step (flood behind the sweep, from the masks the
+                                        # sweep collected; one to eight waves per environment), and its two-launch form
+                                        (28, 28, None), (32, 32, None), (64, 64, None), (100, 40, None), (128, 128, None),
+                                        (64, 64, "two-launch"), (100, 40, "two-launch")])
 def test_containment_rewards_with_circling_agents(wf, monkeypatch, W, H, family):
     """Agents that dig a ring around the fire: the +1000 containment reward (get_reward's A* part,
     environment.py:345-377) must appear exactly when and where the oracle pays it - tiled family
-    (flood in the prologue + per-row board test), generic family (byte board in LDS) and wave family alike."""
+    (flood by the environment's workgroup or in the prologue + per-row board test), generic family (byte board in LDS)
+    and wave family alike."""
     monkeypatch.delenv("WF_FAMILY", raising=False)
-    if family:
+    monkeypatch.delenv("WF_NO_SOLO", raising=False)
+    if family == "two-launch":
+        monkeypatch.setenv("WF_NO_SOLO", "1")
+    elif family:
         monkeypatch.setenv("WF_FAMILY", family)
     B, T = 96, 150
     env = wf.BatchedForestFire(B, width=W, height=H, seed=2, containment=True)
