@@ -331,6 +331,77 @@ def test_one_launch_tiled_step_with_any_strip_height(wf, monkeypatch, W, H, rows
     _run_big_grid(wf, monkeypatch, W, H, 20)
 
 
+@pytest.mark.parametrize("W,H,B,n", [(64, 64, 48, 16), (32, 32, 70, 16), (128, 64, 20, 7), (100, 40, 30, 33), (28, 28, 64, 64),
+                                     (256, 256, 3, 5), (64, 64, 2100, 6)])
+def test_tiled_step_loop_matches_oracle(wf, monkeypatch, W, H, B, n):
+    """n-step calls of the tiled family's one-launch step are ONE launch per share with the step loop inside the kernel
+    (wf_step_tiled<.., SOLO, MULTI>): the workgroup that owns the environment runs its n steps back to back - agent
+    logic, tick, flood, reward, auto-reset - with the caches between the steps dropped.  Against the oracle: rewards and
+    done flags of every step, the state after every call; every other call through the device API with the fused
+    observation of the last step (n - 1 looped steps + one launch that writes it); half of the agents close rings
+    (floods and containment payments inside the loop).  A WF_NO_SOLO_LOOP=1 twin (n launches per call) must agree too.
+    2 100 x 64x64 is past the size where a call goes out as three shares on three streams."""
+    import torch
+    for k in ("WF_NO_SOLO", "WF_NO_SOLO_LOOP", "WF_TILED_ROWS", "WF_FAMILY"):
+        monkeypatch.delenv(k, raising=False)
+    kw = dict(width=W, height=H, seed=9, fuel_range=(3, 12), ignite_ppm=8000, auto_reset=True, containment=True)
+    env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.setenv("WF_NO_SOLO_LOOP", "1")
+    twin = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_NO_SOLO_LOOP", raising=False)
+    parts = 3 if B * W * H >= 8 << 20 else 1
+    assert env.step_kernel == "wf_step_tiled<solo>"
+    assert env._lib.wf_call_launches(env._h, n) == parts and twin._lib.wf_call_launches(twin._h, n) == n * parts
+    env.reset(seed=31)
+    twin.reset(seed=31)
+    op = O.default_params(fuel_lo=3, fuel_hi=12, ignite_ppm=8000, containment=1)
+    planes, envs = O.new_state(B, H, W)
+    O.reset(planes, envs, seed=31, params=op)
+    rng = np.random.default_rng(W + H + n)
+    dev = torch.device("cuda", 0)
+    d_r = torch.empty((n, B), dtype=torch.float64, device=dev)
+    d_d = torch.empty((n, B), dtype=torch.uint8, device=dev)
+    d_obs = torch.empty((B, W, H, 3), dtype=torch.int8, device=dev)
+    fused_obs = H % 4 == 0 and H * W * 3 < 48 * 1024
+    paid = resets = 0
+    for call in range(3 if B > 1000 else 6):
+        a = rng.integers(0, 6, size=(n, B)).astype(np.int8)
+        a[0, :B // 2] = _circle_actions(envs[:B // 2], W, H, rng)
+        a[1:, :B // 2] = a[0, :B // 2]                       # (stale after the first step: still ring-ish diggers)
+        if call % 2:
+            d_a = torch.from_numpy(a).to(dev)
+            torch.cuda.synchronize()
+            env.step_device(d_a, n, d_r, d_d, d_obs=d_obs if fused_obs else None)
+            env.sync()
+            r, d = d_r.cpu().numpy(), d_d.cpu().numpy().astype(bool)
+        else:
+            r, d = env.step_many(a)
+        rt, dt = twin.step_many(a)
+        for k in range(n):
+            stopped = (envs["flags"] & O.F_RUNNING) == 0
+            ro, do = O.step(planes, envs, a[k], op)
+            if stopped.any():
+                O.reset(planes, envs, seed=9, mask=stopped, params=op)
+                ro[stopped], do[stopped] = 0.0, 0
+                resets += int(stopped.sum())
+            paid += int((ro == 1000.0).sum())
+            np.testing.assert_array_equal(r[k], ro, err_msg=f"call {call} step {k}: reward")
+            np.testing.assert_array_equal(d[k], do.astype(bool), err_msg=f"call {call} step {k}: done")
+        np.testing.assert_array_equal(rt, r, err_msg=f"call {call}: reward, n launches against one")
+        np.testing.assert_array_equal(dt, d, err_msg=f"call {call}: done, n launches against one")
+        gp, ge = env.download()
+        np.testing.assert_array_equal(gp, planes, err_msg=f"planes after call {call}")
+        np.testing.assert_array_equal(_envs(ge), envs, err_msg=f"envs after call {call}")
+        if call % 2 and fused_obs:
+            np.testing.assert_array_equal(d_obs.cpu().numpy(), O.get_state(planes), err_msg=f"fused observation of call {call}")
+    tp, te = twin.download()
+    np.testing.assert_array_equal(tp, planes)
+    np.testing.assert_array_equal(_envs(te), envs)
+    assert resets > 0 or n * 6 < 40
+    env.close()
+    twin.close()
+
+
 def _run_big_grid(wf, monkeypatch, W, H, B):
     T = 70
     monkeypatch.delenv("WF_FAMILY", raising=False)

@@ -951,7 +951,42 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
     } else {
         JOIN(c);
     }
-    for (int st = 0; st < n_steps; ++st) {
+    // n-step calls of the tiled family's one-launch step: the steps before the one that writes the observation (all of
+    // them without one) are ONE launch per share, the step loop inside the kernel (wf_step_tiled<.., SOLO, MULTI>)
+    const int solo_rows = tiled_solo(c);
+    int looped = 0;
+    if (n_steps > 1 && !c->knobs.no_solo_loop && wf_tiled_solo_fits(c->H, c->W, solo_rows, c->p.containment != 0, false)) {
+        const bool obs_fused = d_obs && wf_tiled_fused_obs(c->H, c->W) &&
+                               wf_tiled_solo_fits(c->H, c->W, solo_rows, c->p.containment != 0, true);
+        looped = obs_fused ? n_steps - 1 : n_steps;
+    }
+    if (looped > 1) {
+        for (int i = 0; i < parts; ++i) {
+            const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
+            if (lo >= hi) break;
+            WfArgs a = base_args(c);
+            a.batch = hi - lo;
+            a.env_base = (uint32_t)lo;
+            a.planes += (size_t)lo * cells;
+            a.planes_out += (size_t)lo * cells;
+            a.envs += lo;
+            a.reach += (size_t)lo * c->H * 4;
+            a.actions = d_actions ? d_actions + lo : nullptr;
+            a.reward = d_reward ? d_reward + lo : nullptr;
+            a.done = d_done ? d_done + lo : nullptr;
+            a.n_steps = looped;
+            a.step_stride = c->batch;
+            a.update_mask = update_mask;
+            a.sweep_rev = c->knobs.sweep_alt ? (int32_t)(c->sweeps & 1u) : 0;
+            a.obs = nullptr;
+            hipStream_t si = i == 0 ? c->stream : c->side[i - 1];
+            HIP_TRY(c, wf_launch_step_big(c->fam, a, c->d_mode + lo, c->d_acc + (size_t)lo * 4, nullptr, c->p.seed, si, false, solo_rows));
+        }
+        c->sweeps += (unsigned)looped;
+    } else {
+        looped = 0;
+    }
+    for (int st = looped; st < n_steps; ++st) {
         const size_t off = (size_t)st * (size_t)c->batch;
         for (int i = 0; i < parts; ++i) {
             const int lo = i * per, hi = lo + per < c->batch ? lo + per : c->batch;
@@ -1223,7 +1258,10 @@ const char *wf_call_kernel_name(const wf_ctx *c, int n_steps)
 int wf_call_launches(const wf_ctx *c, int n_steps)
 {
     if (!c || n_steps < 1) return 0;
-    if (c->fam != WF_FAM_WAVE) return n_steps * (splits_big(c) ? c->n_parts : 1);      // launch sequences
+    if (c->fam != WF_FAM_WAVE) {                                                        // launch sequences (a call without the observation)
+        const bool loop = n_steps > 1 && !c->knobs.no_solo_loop && wf_tiled_solo_fits(c->H, c->W, tiled_solo(c), c->p.containment != 0, false);
+        return (loop ? 1 : n_steps) * (splits_big(c) ? c->n_parts : 1);
+    }
     const int per_step = splits(c, 1) ? single_step_shape(c).parts : 1;
     if (n_steps == 1) return per_step;
     if (c->p.wind_mode != WF_WIND_CALM) return per_step * n_steps;                      // wind: single-step launches only

@@ -85,6 +85,7 @@ struct WfKnobs {
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
     int tiled_rows;  // WF_TILED_ROWS: rows per strip of the one-launch tiled step (default: wf_tiled_solo_rows)
+    int no_solo_loop; // WF_NO_SOLO_LOOP: n-step calls of the one-launch tiled step as n launches, not one launch with the step loop
     int no_solo;     // WF_NO_SOLO: tiled grids one workgroup covers step as the larger ones do (wf_tiled_prologue -> wf_step_tiled), not in one launch
     int no_onegen;   // WF_NO_ONEGEN: never the one-generation shape of a single step (4 environments per wave, shared agent phases, 3 parts; wf_abi.cpp: single_step_shape)
     int no_prio;     // WF_NO_PRIO: never set WF_HOT_PROGRESS_PRIO

@@ -327,8 +327,8 @@ __device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e
 // tick, the reachability flood when the dig called for one (solo_flood, behind the sweep: only that workgroup is late,
 // not a launch), World.RUNNING / reward / done from reductions in LDS: one launch per step, nothing but the cells, the
 // record and the board touched in memory.
-template <bool OBS, int P, bool SOLO>
-__global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_tiled(const WfArgs a, const uint8_t *mode, uint32_t *acc, const u64 *outer, const uint32_t tr)
+template <bool OBS, int P, bool SOLO, bool MULTI = false>
+__global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_tiled(const WfArgs a0, const uint8_t *mode, uint32_t *acc, const u64 *outer, const uint32_t tr)
 {
     constexpr int MAXW = SOLO ? WF_SOLO_MAX_WAVES : 4;  // waves per workgroup (SOLO: as many as it takes to cover the grid)
     __shared__ u64 halo[MAXW][2][4];                 // [wave][first,last row of each of its segments][component]
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
     const uint32_t WR = (uint32_t)P * tr;                        // rows per wave (tr per strip: TR, fewer for small SOLO grids)
     const uint32_t lane = __lane_id();
     const uint32_t wv = rfl(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, LW = W >> 2;
+    const uint32_t H = (uint32_t)a0.H, W = (uint32_t)a0.W, LW = W >> 2;
     const uint32_t gx = SOLO ? 1u : (H + nw * WR - 1u) / (nw * WR);     // workgroups per environment
     // (workgroups are dispatched in blockIdx order: a reversed step walks the batch from its far end)
-    const uint32_t bid = a.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const uint32_t bid = a0.sweep_rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
     const uint32_t e = bid / gx;
     const uint32_t r0 = ((bid % gx) * nw + wv) * WR;             // segment 0's first row; segment s: r0 + 16 s
     const uint32_t r1 = min(r0 + tr, H);                         // end of the sweep (segment 0's rows)
@@ -355,188 +355,214 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
     pk.row_off = (P == 1 ? 0u : lane / LWP) * tr;
     pk.ql = P == 1 ? lane : lane % LWP;
     pk.col_ok = pk.ql < LW;
-    pk.rivers = (a.hot_flags & WF_HOT_RIVERS) != 0;
-    pk.rare = (a.hot_flags & WF_HOT_RARE) != 0;
+    pk.rivers = (a0.hot_flags & WF_HOT_RIVERS) != 0;
+    pk.rare = (a0.hot_flags & WF_HOT_RARE) != 0;
     pk.XL = Pack<P>::X0 << (LW - 1u);
     const uint32_t lane_cell0 = pk.row_off * LW + pk.ql;         // this lane's quad index at sweep position 0 (+ r * LW)
-    const uint32_t ign = (uint32_t)a.ignite_count;
+    const uint32_t ign = (uint32_t)a0.ignite_count;
     u64 *const collect = reinterpret_cast<u64 *>(dyn_lds);
-    uint8_t *const obs_lds = dyn_lds + (SOLO && (a.hot_flags & WF_HOT_CONTAINMENT) ? nw * (uint32_t)(TR * COLLECT_WORDS * 8) : 0u);
-    uint32_t md;
-    if constexpr (SOLO) {
-        if (threadIdx.x == 0) {
-            uint4 ev;
-            bool have_record;
-            s_word[0] = big_pre_env(a, e, ev, have_record);
-            s_ev = ev;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the touched bytes, for the other waves of this CU
+    uint8_t *const obs_lds = dyn_lds + (SOLO && (a0.hot_flags & WF_HOT_CONTAINMENT) ? nw * (uint32_t)(TR * COLLECT_WORDS * 8) : 0u);
+    // One step of the environment (SOLO) / of this workgroup's rows; `a`: the launch's arguments as that step sees them
+    auto one_step = [&](const WfArgs &a) {
+        uint32_t md;
+        if constexpr (SOLO) {
+            if (threadIdx.x == 0) {
+                uint4 ev;
+                bool have_record;
+                s_word[0] = big_pre_env(a, e, ev, have_record);
+                s_ev = ev;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the touched bytes, for the other waves of this CU
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            md = rfl(s_word[0]);
+        } else {
+            md = mode[e];
+        }
+        const uint32_t wg_row0 = (bid % gx) * nw * WR;
+        const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
+        int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
+        if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
+            const bool fresh = (md & MODE_MASK) == MODE_RESET;  // auto-reset: World.reset() of this environment's cells, here
+            if (fresh || OBS) {                                // (a frozen one still owes its observation)
+                uint4 *rows = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane_cell0;
+                const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);          // fresh: written by the prologue
+                const EnvKey key(a.cold->p.seed, a.cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
+                const ResetLaw L = reset_law(a, ev);
+                const bool rivers = fresh && a.cold->p.make_rivers != 0;
+                bool border_fire = false;
+                // reset_map's river: the wave walks it once and keeps the columns of its own rows (0xffff: none)
+                uint16_t *river_col = river_tab[wv];
+                if (rivers) {
+                    river_col[lane] = 0xffffu;
+                    river_cells(key, (int)W, (int)H, [&](int x, int y) {
+                        if ((uint32_t)y - r0 < WR && lane == 0) river_col[(uint32_t)y - r0] = (uint16_t)x;
+                    });
+                }
+                for (uint32_t r = r0; r < r1; ++r) {
+                    const uint32_t row = r + pk.row_off;
+                    const bool active = pk.col_ok && row < H;
+                    uint32_t cq[4] = { 0, 0, 0, 0 };
+                    if (fresh) {
+                        if (active) {
+                            const uint32_t rcol = rivers ? (uint32_t)river_col[row - r0] : 0xffffu;
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) cq[j] = reset_cell(L, key, row * W + 4u * pk.ql + (uint32_t)j, 4u * pk.ql + (uint32_t)j, row, rcol, border_fire);
+                            rows[r * LW] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+                        }
+                    } else if (active) {
+                        const uint4 q = rows[r * LW];
+                        cq[0] = q.x; cq[1] = q.y; cq[2] = q.z; cq[3] = q.w;
+                    }
+                    if constexpr (OBS) {
+                        if (active) stage_obs_row(ot, row, pk.ql, cq);
+                    }
+                }
+                if (__ballot(border_fire) && lane == 0)
+                    atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+            }
+            if constexpr (OBS) {
+                __syncthreads();
+                flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
+            }
+            return;
+        }
+        const bool step = (a.update_mask & 1ull) != 0;
+        const bool reach_test = (md & MODE_PRECHECK) != 0;
+        const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4], bit = quad of the row
+        // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane_cell0;
+        const TiledDst dst = { __builtin_amdgcn_make_buffer_rsrc(a.planes + (size_t)e * H * W, 0, (int)(H * W * 4u), 0x00020000), lane_cell0 * 16u };
+        const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
+
+        // ---- prologue: masks of every segment's first and last row (original state) -> LDS
+        uint4 first = inert, last = inert, second = inert;
+        u64 Sf[4] = { 0, 0, 0, 0 }, Sl[4] = { 0, 0, 0, 0 };
+        if (has_rows) {
+            if (pk.col_ok && r0 + pk.row_off < H) first = src[r0 * LW];
+            if (pk.col_ok && r1 - 1u + pk.row_off < H) last = src[(r1 - 1u) * LW];
+            // (the sweep's second row, requested here: it arrives while the halos are exchanged)
+            if (r0 + 1 < r1 && pk.col_ok && r0 + 1u + pk.row_off < H) second = src[(r0 + 1u) * LW];
+            still_masks(first, Sf);
+            still_masks(last, Sl);
+        }
+        if (lane == 0) {
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) { halo[wv][0][j] = Sf[j]; halo[wv][1][j] = Sl[j]; }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        md = rfl(s_word[0]);
-    } else {
-        md = mode[e];
-    }
-    const uint32_t wg_row0 = (bid % gx) * nw * WR;
-    const ObsTile ot = { obs_lds, W * 3u, wg_row0 };
-    int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
-    if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
-        const bool fresh = (md & MODE_MASK) == MODE_RESET;  // auto-reset: World.reset() of this environment's cells, here
-        if (fresh || OBS) {                                // (a frozen one still owes its observation)
-            uint4 *rows = reinterpret_cast<uint4 *>(a.planes) + (size_t)e * H * LW + lane_cell0;
-            const uint4 ev = *reinterpret_cast<const uint4 *>(&a.envs[e]);          // fresh: written by the prologue
-            const EnvKey key(a.cold->p.seed, a.cold->p.env_id0 + a.env_base + (u64)e, ev.z - 1u);
-            const ResetLaw L = reset_law(a, ev);
-            const bool rivers = fresh && a.cold->p.make_rivers != 0;
-            bool border_fire = false;
-            // reset_map's river: the wave walks it once and keeps the columns of its own rows (0xffff: none)
-            uint16_t *river_col = river_tab[wv];
-            if (rivers) {
-                river_col[lane] = 0xffffu;
-                river_cells(key, (int)W, (int)H, [&](int x, int y) {
-                    if ((uint32_t)y - r0 < WR && lane == 0) river_col[(uint32_t)y - r0] = (uint16_t)x;
-                });
+        TiledAcc A = { 0, 0, 0, 0, 0, 0 };
+        if (has_rows) {                                        // (a wave without rows of its own still flushes and arrives below)
+
+        // masks of the row above / below every segment (original state).  Segment 0's row above: the last segment of the
+        // wave before (LDS) or of the workgroup before (the saved outer halos); the last segment's row below likewise; the
+        // segments in between see each other's last / first rows through a shift of one segment
+        u64 Sp[4] = { 0, 0, 0, 0 }, Sb[4] = { 0, 0, 0, 0 };
+        if (r0 > 0) {
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 v = wv > 0 ? (halo[wv - 1][1][j] >> (LWP * (uint32_t)(P - 1))) : outer[(size_t)bid * 8 + j];
+                Sp[j] = (((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0;
             }
-            for (uint32_t r = r0; r < r1; ++r) {
-                const uint32_t row = r + pk.row_off;
-                const bool active = pk.col_ok && row < H;
-                uint32_t cq[4] = { 0, 0, 0, 0 };
-                if (fresh) {
-                    if (active) {
-                        const uint32_t rcol = rivers ? (uint32_t)river_col[row - r0] : 0xffffu;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) cq[j] = reset_cell(L, key, row * W + 4u * pk.ql + (uint32_t)j, 4u * pk.ql + (uint32_t)j, row, rcol, border_fire);
-                        rows[r * LW] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
-                    }
-                } else if (active) {
-                    const uint4 q = rows[r * LW];
-                    cq[0] = q.x; cq[1] = q.y; cq[2] = q.z; cq[3] = q.w;
-                }
-                if constexpr (OBS) {
-                    if (active) stage_obs_row(ot, row, pk.ql, cq);
-                }
+        }
+        if (r0 + WR < H) {
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 v = wv + 1u < nw ? halo[wv + 1][0][j] : outer[(size_t)bid * 8 + 4 + j];
+                Sb[j] = ((((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0) << (LWP * (uint32_t)(P - 1));
             }
-            if (__ballot(border_fire) && lane == 0)
-                atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
         }
-        if constexpr (OBS) {
-            __syncthreads();
-            flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
+        if constexpr (P > 1) {
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Sp[j] |= Sl[j] << LWP;
+                Sb[j] |= Sf[j] >> LWP;
+            }
         }
-        return;
-    }
-    const bool step = (a.update_mask & 1ull) != 0;
-    const bool reach_test = (md & MODE_PRECHECK) != 0;
-    const u64 *reach_e = a.reach + (size_t)e * H * 4;      // board rows: u64[H][4], bit = quad of the row
-    // per-env base pointers (64-bit, once) + 32-bit uint4 indices inside the env (H*W/4 < 2^32)
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.planes) + (size_t)e * H * LW + lane_cell0;
-    const TiledDst dst = { __builtin_amdgcn_make_buffer_rsrc(a.planes + (size_t)e * H * W, 0, (int)(H * W * 4u), 0x00020000), lane_cell0 * 16u };
-    const uint4 inert = make_uint4(WF_DIRT, WF_DIRT, WF_DIRT, WF_DIRT);
 
-    // ---- prologue: masks of every segment's first and last row (original state) -> LDS
-    uint4 first = inert, last = inert, second = inert;
-    u64 Sf[4] = { 0, 0, 0, 0 }, Sl[4] = { 0, 0, 0, 0 };
-    if (has_rows) {
-        if (pk.col_ok && r0 + pk.row_off < H) first = src[r0 * LW];
-        if (pk.col_ok && r1 - 1u + pk.row_off < H) last = src[(r1 - 1u) * LW];
-        // (the sweep's second row, requested here: it arrives while the halos are exchanged)
-        if (r0 + 1 < r1 && pk.col_ok && r0 + 1u + pk.row_off < H) second = src[(r0 + 1u) * LW];
-        still_masks(first, Sf);
-        still_masks(last, Sl);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { halo[wv][0][j] = Sf[j]; halo[wv][1][j] = Sl[j]; }
-    }
-    __syncthreads();
-    TiledAcc A = { 0, 0, 0, 0, 0, 0 };
-    if (has_rows) {                                        // (a wave without rows of its own still flushes and arrives below)
-
-    // masks of the row above / below every segment (original state).  Segment 0's row above: the last segment of the
-    // wave before (LDS) or of the workgroup before (the saved outer halos); the last segment's row below likewise; the
-    // segments in between see each other's last / first rows through a shift of one segment
-    u64 Sp[4] = { 0, 0, 0, 0 }, Sb[4] = { 0, 0, 0, 0 };
-    if (r0 > 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u64 v = wv > 0 ? (halo[wv - 1][1][j] >> (LWP * (uint32_t)(P - 1))) : outer[(size_t)bid * 8 + j];
-            Sp[j] = (((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0;
+        // ---- sweep
+        u64 *const collect_w = collect + wv * (uint32_t)(TR * COLLECT_WORDS);
+        auto sweep = [&](auto ST, auto RM) {
+            tiled_sweep<decltype(ST)::value, decltype(RM)::value, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, second, Sf, Sp, Sb, reach_e, collect_w, A);
+        };
+        typedef std::integral_constant<int, REACH_NONE> RNone;
+        typedef std::integral_constant<int, REACH_TEST> RTest;
+        typedef std::integral_constant<int, SOLO ? REACH_COLLECT : REACH_TEST> RCollect;
+        const bool collecting = SOLO && (md & MODE_FLOOD);                  // (MODE_FLOOD: only ever with MODE_PRECHECK)
+        if (step) {
+            if (collecting) sweep(std::true_type{}, RCollect{});
+            else if (reach_test) sweep(std::true_type{}, RTest{});
+            else sweep(std::true_type{}, RNone{});
+        } else {
+            if (collecting) sweep(std::false_type{}, RCollect{});
+            else if (reach_test) sweep(std::false_type{}, RTest{});
+            else sweep(std::false_type{}, RNone{});
         }
-    }
-    if (r0 + WR < H) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u64 v = wv + 1u < nw ? halo[wv + 1][0][j] : outer[(size_t)bid * 8 + 4 + j];
-            Sb[j] = ((((u64)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v)) & Pack<P>::SEG0) << (LWP * (uint32_t)(P - 1));
+        A.bhit |= ((A.ign_x0 & Pack<P>::X0) | (A.ign_xl & pk.XL)) ? 1u : 0u;      // x == 0 / x == W-1 columns
+        if (!SOLO && lane == 0) {
+            // device-scope atomics are performed at the memory side (the per-XCD L2s are not coherent with each other);
+            // the RETURNING forms, consumed, make the wave wait until they have been
+            const uint32_t R = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
+            uint32_t o0 = 0, o1 = 0;
+            if (R) o0 = atomicOr(&acc[4 * e], R);
+            if (A.healthy) o1 = atomicAdd(&acc[4 * e + 1], A.healthy);
+            asm volatile("" :: "v"(o0), "v"(o1));
         }
-    }
-    if constexpr (P > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Sp[j] |= Sl[j] << LWP;
-            Sb[j] |= Sf[j] >> LWP;
+        }   // has_rows
+        if (SOLO && lane == 0) {
+            s_red[wv][0] = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
+            s_red[wv][1] = A.healthy;
         }
-    }
-
-    // ---- sweep
-    u64 *const collect_w = collect + wv * (uint32_t)(TR * COLLECT_WORDS);
-    auto sweep = [&](auto ST, auto RM) {
-        tiled_sweep<decltype(ST)::value, decltype(RM)::value, OBS, P>(r0, r1, H, LW, ign, pk, src, dst, ot, first, second, Sf, Sp, Sb, reach_e, collect_w, A);
-    };
-    typedef std::integral_constant<int, REACH_NONE> RNone;
-    typedef std::integral_constant<int, REACH_TEST> RTest;
-    typedef std::integral_constant<int, SOLO ? REACH_COLLECT : REACH_TEST> RCollect;
-    const bool collecting = SOLO && (md & MODE_FLOOD);                  // (MODE_FLOOD: only ever with MODE_PRECHECK)
-    if (step) {
-        if (collecting) sweep(std::true_type{}, RCollect{});
-        else if (reach_test) sweep(std::true_type{}, RTest{});
-        else sweep(std::true_type{}, RNone{});
-    } else {
-        if (collecting) sweep(std::false_type{}, RCollect{});
-        else if (reach_test) sweep(std::false_type{}, RTest{});
-        else sweep(std::false_type{}, RNone{});
-    }
-    A.bhit |= ((A.ign_x0 & Pack<P>::X0) | (A.ign_xl & pk.XL)) ? 1u : 0u;      // x == 0 / x == W-1 columns
-    if (!SOLO && lane == 0) {
-        // device-scope atomics are performed at the memory side (the per-XCD L2s are not coherent with each other);
-        // the RETURNING forms, consumed, make the wave wait until they have been
-        const uint32_t R = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
-        uint32_t o0 = 0, o1 = 0;
-        if (R) o0 = atomicOr(&acc[4 * e], R);
-        if (A.healthy) o1 = atomicAdd(&acc[4 * e + 1], A.healthy);
-        asm volatile("" :: "v"(o0), "v"(o1));
-    }
-    }   // has_rows
-    if (SOLO && lane == 0) {
-        s_red[wv][0] = A.anyfire | (A.bhit << 1) | (A.reach_hit << 2);
-        s_red[wv][1] = A.healthy;
-    }
-    __syncthreads();
-    if constexpr (OBS) flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
-    if constexpr (SOLO) {
-        uint32_t fl = 0;
-        if (md & MODE_FLOOD) {
-            if constexpr (OBS) __syncthreads();                   // the flood's boards take the observation tile's place
-            fl = solo_flood<P>(a, e, tr, collect, reinterpret_cast<u64 *>(obs_lds), &s_word[1]);
+        __syncthreads();
+        if constexpr (OBS) flush_obs_tile(ot, min(nw * WR, H - wg_row0), W, H, obs_e);
+        if constexpr (SOLO) {
+            uint32_t fl = 0;
+            if (md & MODE_FLOOD) {
+                if constexpr (OBS) __syncthreads();                   // the flood's boards take the observation tile's place
+                fl = solo_flood<P>(a, e, tr, collect, reinterpret_cast<u64 *>(obs_lds), &s_word[1]);
+            }
+            if (threadIdx.x == 0) {
+                uint32_t Aw = (fl & 1u) << 2, healthy = 0;
+                for (uint32_t w = 0; w < nw; ++w) { Aw |= s_red[w][0]; healthy += s_red[w][1]; }
+                // (a board that did not converge - never, with the H*W bound - would not be trusted later)
+                big_post_env(a, e, md, Aw, healthy, (fl & 2u) ? (uint32_t)WF_F_REACH_VALID : 0u, s_ev);
+            }
+            return;
         }
+        // ---- World.RUNNING / reward / done of the environment: by whichever of its gx workgroups arrives last (every wave
+        // of this workgroup has its reduction atomics behind it: the barrier above).  No data but the atomically updated
+        // words passes between the workgroups, so no cache write-back fence is needed.
         if (threadIdx.x == 0) {
-            uint32_t Aw = (fl & 1u) << 2, healthy = 0;
-            for (uint32_t w = 0; w < nw; ++w) { Aw |= s_red[w][0]; healthy += s_red[w][1]; }
-            // (a board that did not converge - never, with the H*W bound - would not be trusted later)
-            big_post_env(a, e, md, Aw, healthy, (fl & 2u) ? (uint32_t)WF_F_REACH_VALID : 0u, s_ev);
+            const uint32_t ticket = atomicAdd(&acc[4 * e + 2], 1u);
+            if (ticket == gx - 1u) {
+                const uint32_t Aw = atomicExch(&acc[4 * e], 0u), healthy = atomicExch(&acc[4 * e + 1], 0u);
+                atomicExch(&acc[4 * e + 2], 0u);
+                big_post_env(a, e, md, Aw, healthy);
+            }
         }
-        return;
-    }
-    // ---- World.RUNNING / reward / done of the environment: by whichever of its gx workgroups arrives last (every wave
-    // of this workgroup has its reduction atomics behind it: the barrier above).  No data but the atomically updated
-    // words passes between the workgroups, so no cache write-back fence is needed.
-    if (threadIdx.x == 0) {
-        const uint32_t ticket = atomicAdd(&acc[4 * e + 2], 1u);
-        if (ticket == gx - 1u) {
-            const uint32_t Aw = atomicExch(&acc[4 * e], 0u), healthy = atomicExch(&acc[4 * e + 1], 0u);
-            atomicExch(&acc[4 * e + 2], 0u);
-            big_post_env(a, e, md, Aw, healthy);
+    };
+    if constexpr (MULTI) {
+        // n_steps steps of the environment in ONE launch (SOLO only: the workgroup owns the environment, so a step's stores
+        // have to reach no further than this CU).  Between two steps: every store of the step issued and acknowledged, the
+        // workgroup together, then the vector L1 and the scalar cache dropped - a border flag set by an atomic and the
+        // reachability board (written by vector stores, read back through the scalar cache) bypass them.
+        static_assert(SOLO && !OBS, "the step loop is the one-launch form without the observation");
+        const uint32_t n = (uint32_t)a0.n_steps, stride = (uint32_t)a0.step_stride;
+        for (uint32_t st = 0; st < n; ++st) {
+            WfArgs as = a0;
+            const size_t off = (size_t)st * stride;
+            as.actions = a0.actions ? a0.actions + off : nullptr;
+            as.reward = a0.reward ? a0.reward + off : nullptr;
+            as.done = a0.done ? a0.done + off : nullptr;
+            as.update_mask = (a0.update_mask >> st) & 1ull;
+            one_step(as);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            asm volatile("buffer_inv sc1" ::: "memory");
+            __builtin_amdgcn_s_dcache_inv();
         }
+    } else {
+        one_step(a0);
     }
 }
 
@@ -779,9 +805,15 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
         const size_t lds = solo_lds(ts, a.H, a.W, containment, a.obs != nullptr);
         const dim3 grid((unsigned)a.batch), block(64u * (unsigned)ts.nw);
 #define WF_SOLO_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr, (uint32_t)ts.tr)
+#define WF_SOLO_LOOP(P) hipLaunchKernelGGL((wf_step_tiled<false, P, true, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr, (uint32_t)ts.tr)
+        if (a.n_steps > 1) {        // the step loop (the caller keeps the observation's step out of it)
+            if (a.obs) return hipErrorInvalidValue;
+            if (ts.P == 4) WF_SOLO_LOOP(4); else if (ts.P == 2) WF_SOLO_LOOP(2); else WF_SOLO_LOOP(1);
+        } else
         if (a.obs) { if (ts.P == 4) WF_SOLO_LAUNCH(true, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(true, 2); else WF_SOLO_LAUNCH(true, 1); }
         else { if (ts.P == 4) WF_SOLO_LAUNCH(false, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(false, 2); else WF_SOLO_LAUNCH(false, 1); }
 #undef WF_SOLO_LAUNCH
+#undef WF_SOLO_LOOP
         return hipGetLastError();
     }
     if (fam == WF_FAM_TILED) {
