@@ -332,7 +332,7 @@ def test_one_launch_tiled_step_with_any_strip_height(wf, monkeypatch, W, H, rows
 
 
 @pytest.mark.parametrize("W,H,B,n", [(64, 64, 48, 16), (32, 32, 70, 16), (128, 64, 20, 7), (100, 40, 30, 33), (28, 28, 64, 64),
-                                     (256, 256, 3, 5), (64, 64, 2100, 6)])
+                                     (256, 256, 3, 5), (64, 64, 2100, 6), (32, 32, 9000, 4)])
 def test_tiled_step_loop_matches_oracle(wf, monkeypatch, W, H, B, n):
     """n-step calls of the tiled family's one-launch step are ONE launch per share with the step loop inside the kernel
     (wf_step_tiled<.., SOLO, MULTI>): the workgroup that owns the environment runs its n steps back to back - agent
@@ -340,12 +340,19 @@ def test_tiled_step_loop_matches_oracle(wf, monkeypatch, W, H, B, n):
     done flags of every step, the state after every call; every other call through the device API with the fused
     observation of the last step (n - 1 looped steps + one launch that writes it); half of the agents close rings
     (floods and containment payments inside the loop).  A WF_NO_SOLO_LOOP=1 twin (n launches per call) must agree too.
-    2 100 x 64x64 is past the size where a call goes out as three shares on three streams."""
+    2 100 x 64x64 is past the size where a call goes out as three shares on three streams; 9 000 x 32x32 is a job of more
+    waves than the chip holds at once, which steps with n launches by default (here: WF_SOLO_LOOP=1)."""
     import torch
-    for k in ("WF_NO_SOLO", "WF_NO_SOLO_LOOP", "WF_TILED_ROWS", "WF_FAMILY"):
+    for k in ("WF_NO_SOLO", "WF_NO_SOLO_LOOP", "WF_SOLO_LOOP", "WF_TILED_ROWS", "WF_FAMILY"):
         monkeypatch.delenv(k, raising=False)
     kw = dict(width=W, height=H, seed=9, fuel_range=(3, 12), ignite_ppm=8000, auto_reset=True, containment=True)
+    if B >= 9000:
+        plain = wf.BatchedForestFire(B, **kw)
+        assert plain._lib.wf_call_launches(plain._h, n) == 3 * n
+        plain.close()
+        monkeypatch.setenv("WF_SOLO_LOOP", "1")
     env = wf.BatchedForestFire(B, **kw)
+    monkeypatch.delenv("WF_SOLO_LOOP", raising=False)
     monkeypatch.setenv("WF_NO_SOLO_LOOP", "1")
     twin = wf.BatchedForestFire(B, **kw)
     monkeypatch.delenv("WF_NO_SOLO_LOOP", raising=False)

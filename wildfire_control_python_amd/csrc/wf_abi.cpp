@@ -307,6 +307,19 @@ int tiled_solo(const wf_ctx *c)
     return c->fam == WF_FAM_TILED && !c->knobs.no_solo ? wf_tiled_solo_rows(c->H, c->W, c->knobs.tiled_rows, c->batch) : 0;
 }
 
+// n-step calls of the tiled family's one-launch step as ONE launch per share, the step loop inside the kernel
+// (wf_step_tiled<.., SOLO, MULTI>).  For jobs of fewer than WF_TILED_SOLO_WAVES waves - about what the chip holds at
+// once: the loop's workgroups stay where they are and pay no launch boundary per step (us per step, loop / n launches:
+// 512 x 64x64 11.1 / 18.3, 2 048 x 64x64 14.9 / 20.5, 512 x 128x128 15.0 / 21.4, 256 x 256x256 26.3 / 34.5) - while a
+// job of several generations of waves is better off re-dealt to the CUs every step (4 096 x 64x64 26.2 / 24.4,
+// 16 384 x 32x32 47.8 / 41.6).
+bool solo_loop_serves(const wf_ctx *c, int n_steps)
+{
+    const int rows = tiled_solo(c);
+    if (n_steps < 2 || c->knobs.no_solo_loop || !wf_tiled_solo_fits(c->H, c->W, rows, c->p.containment != 0, false)) return false;
+    return c->knobs.solo_loop || (long long)c->batch * wf_tiled_solo_waves(c->H, c->W, rows) < WF_TILED_SOLO_WAVES;
+}
+
 bool splits_big(const wf_ctx *c)
 {
     return c->fam != WF_FAM_WAVE && c->own_stream && c->n_parts > 1 && c->batch >= 2 * c->n_parts &&
@@ -955,7 +968,7 @@ int wf_step_obs_device(wf_ctx *c, const int8_t *d_actions, int n_steps, uint64_t
     // them without one) are ONE launch per share, the step loop inside the kernel (wf_step_tiled<.., SOLO, MULTI>)
     const int solo_rows = tiled_solo(c);
     int looped = 0;
-    if (n_steps > 1 && !c->knobs.no_solo_loop && wf_tiled_solo_fits(c->H, c->W, solo_rows, c->p.containment != 0, false)) {
+    if (solo_loop_serves(c, n_steps)) {
         const bool obs_fused = d_obs && wf_tiled_fused_obs(c->H, c->W) &&
                                wf_tiled_solo_fits(c->H, c->W, solo_rows, c->p.containment != 0, true);
         looped = obs_fused ? n_steps - 1 : n_steps;
@@ -1259,8 +1272,7 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
 {
     if (!c || n_steps < 1) return 0;
     if (c->fam != WF_FAM_WAVE) {                                                        // launch sequences (a call without the observation)
-        const bool loop = n_steps > 1 && !c->knobs.no_solo_loop && wf_tiled_solo_fits(c->H, c->W, tiled_solo(c), c->p.containment != 0, false);
-        return (loop ? 1 : n_steps) * (splits_big(c) ? c->n_parts : 1);
+        return (solo_loop_serves(c, n_steps) ? 1 : n_steps) * (splits_big(c) ? c->n_parts : 1);
     }
     const int per_step = splits(c, 1) ? single_step_shape(c).parts : 1;
     if (n_steps == 1) return per_step;

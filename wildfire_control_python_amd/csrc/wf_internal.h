@@ -85,7 +85,8 @@ struct WfKnobs {
     int no_resident; // unless WF_RESIDENT is set: the rows kernel's step loop goes through L2, not through an LDS mirror
     int graph;       // WF_GRAPH: wave family, own streams: every distinct wf_step*_device call is captured into a HIP graph and replayed
     int tiled_rows;  // WF_TILED_ROWS: rows per strip of the one-launch tiled step (default: wf_tiled_solo_rows)
-    int no_solo_loop; // WF_NO_SOLO_LOOP: n-step calls of the one-launch tiled step as n launches, not one launch with the step loop
+    int no_solo_loop; // WF_NO_SOLO_LOOP: n-step calls of the one-launch tiled step as n launches, never one launch with the step loop
+    int solo_loop;    // WF_SOLO_LOOP: ... always the step loop (default: for jobs of fewer than WF_TILED_SOLO_WAVES waves, wf_abi.cpp: solo_loop_serves)
     int no_solo;     // WF_NO_SOLO: tiled grids one workgroup covers step as the larger ones do (wf_tiled_prologue -> wf_step_tiled), not in one launch
     int no_onegen;   // WF_NO_ONEGEN: never the one-generation shape of a single step (4 environments per wave, shared agent phases, 3 parts; wf_abi.cpp: single_step_shape)
     int no_prio;     // WF_NO_PRIO: never set WF_HOT_PROGRESS_PRIO
@@ -138,6 +139,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
                               int solo_rows);
 // rows per strip of the tiled family's one-launch step of this shape (0: the shape needs several workgroups per environment)
 int wf_tiled_solo_rows(int H, int W, int want, int batch);
+int wf_tiled_solo_waves(int H, int W, int rows);   // waves of such a workgroup
 bool wf_tiled_solo_fits(int H, int W, int rows, bool containment, bool obs);   // ... and such a launch's LDS fits (else: the two-launch form)
 #define WF_SOLO_MAX_WAVES 16          // waves of a SOLO workgroup
 #define WF_TILED_MIN_ROWS 8           // ... never shorter than this for the sake of more waves

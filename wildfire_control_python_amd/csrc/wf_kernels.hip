@@ -661,6 +661,7 @@ void wf_read_knobs(WfKnobs *k)
     k->no_onegen = set("WF_NO_ONEGEN");
     k->no_solo = set("WF_NO_SOLO");
     k->no_solo_loop = set("WF_NO_SOLO_LOOP");
+    k->solo_loop = set("WF_SOLO_LOOP");
     k->tiled_rows = num("WF_TILED_ROWS", 0);
 }
 

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
                 uint4 ev;
                 bool have_record;
                 s_word[0] = big_pre_env(a, e, ev, have_record);
+                s_word[1] = 0;
                 s_ev = ev;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the touched bytes, for the other waves of this CU
             }
@@ -418,8 +419,18 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
                         if (active) stage_obs_row(ot, row, pk.ql, cq);
                     }
                 }
-                if (__ballot(border_fire) && lane == 0)
-                    atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+                if (__ballot(border_fire) && lane == 0) {
+                    // (SOLO: through LDS and the first thread's plain store - an atomic is performed at the L2 and would leave
+                    // this CU's L1 with the old record, which the step loop's next step reads)
+                    if constexpr (SOLO) atomicOr(&s_word[1], 1u);
+                    else atomicOr(reinterpret_cast<uint32_t *>(&a.envs[e]) + 1, (uint32_t)WF_F_BORDER);
+                }
+            }
+            if constexpr (SOLO) {
+                if (fresh) {
+                    __syncthreads();
+                    if (threadIdx.x == 0 && s_word[1]) reinterpret_cast<uint32_t *>(&a.envs[e])[1] |= (uint32_t)WF_F_BORDER;
+                }
             }
             if constexpr (OBS) {
                 __syncthreads();
@@ -543,9 +554,10 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
     };
     if constexpr (MULTI) {
         // n_steps steps of the environment in ONE launch (SOLO only: the workgroup owns the environment, so a step's stores
-        // have to reach no further than this CU).  Between two steps: every store of the step issued and acknowledged, the
-        // workgroup together, then the vector L1 and the scalar cache dropped - a border flag set by an atomic and the
-        // reachability board (written by vector stores, read back through the scalar cache) bypass them.
+        // have to reach no further than this CU, whose waves share one vector L1).  Between two steps: every store of the
+        // step issued and acknowledged, the workgroup together, and the scalar cache dropped - the reachability board is
+        // written by vector stores and read back through it.  (Dropping the vector L1 as well - buffer_inv sc1, which also
+        // invalidates L2 lines - made a step of 4 096 x 64x64 66 us instead of 24.)
         static_assert(SOLO && !OBS, "the step loop is the one-launch form without the observation");
         const uint32_t n = (uint32_t)a0.n_steps, stride = (uint32_t)a0.step_stride;
         for (uint32_t st = 0; st < n; ++st) {
@@ -558,7 +570,6 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
             one_step(as);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
-            asm volatile("buffer_inv sc1" ::: "memory");
             __builtin_amdgcn_s_dcache_inv();
         }
     } else {
@@ -785,6 +796,7 @@ static size_t solo_lds(const TiledShape &ts, int H, int W, bool containment, boo
     const size_t obs_lds = obs ? (size_t)ts.rows_per_wg * W * 3 + 16 : 0;
     return collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
 }
+int wf_tiled_solo_waves(int H, int W, int rows) { return rows > 0 ? tiled_shape(H, W, rows, WF_SOLO_MAX_WAVES).nw : 0; }
 bool wf_tiled_solo_fits(int H, int W, int rows, bool containment, bool obs)
 {
     return rows > 0 && solo_lds(tiled_shape(H, W, rows, WF_SOLO_MAX_WAVES), H, W, containment, obs) <= 64 * 1024 - 4096;
