@@ -239,6 +239,13 @@ int wf_call_launches(const wf_ctx *ctx, int n_steps);   /* kernel launches behin
 const char *wf_call_kernel_name(const wf_ctx *ctx, int n_steps);   /* the kernel behind that call (an n-step call without
                                                          * actions of a large batch may run on wf_step_ticks where this one does not) */
 
+/* Introspection without a context (touches no device): how `batch` grids of height x width would be stepped by default.
+ * Returns the kernel family as wf_kernel_name names it ("wave", "tiled" or "cells" as a prefix is enough for callers:
+ * 1 = wave family, 2 = tiled, 3 = generic).  For the tiled family also: *one_launch = 1 if a step is one launch of one
+ * workgroup per environment (0: wf_tiled_prologue -> wf_step_tiled), *rows = rows per strip and *waves = waves per
+ * workgroup of that form, *step_loop = 1 if an n-step call runs its steps inside one launch.  Any pointer may be NULL. */
+int wf_step_plan(int height, int width, int batch, int *one_launch, int *rows, int *waves, int *step_loop);
+
 /* Experiments and tests only: the WF_* environment switches (kernel variant, split on/off ...) are read once in
  * wf_create; this re-reads them for an existing context (synchronises; WF_SPLIT itself stays as created). */
 int wf_reload_env(wf_ctx *ctx);

@@ -40,6 +40,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.wf_strerror(-3).decode().startswith("no usable HIP device")
 
 
+def test_step_plan_of_the_kernel_families():
+    """Host logic, no device: which family takes a grid shape and how the tiled family cuts its step (wf_step_plan) -
+    the sizes DESIGN.md section 5 quotes."""
+    lib = N.lib()
+
+    def plan(H, W, B):
+        v = [ctypes.c_int(-1) for _ in range(4)]
+        fam = lib.wf_step_plan(H, W, B, *[ctypes.byref(x) for x in v])
+        return (fam,) + tuple(x.value for x in v)
+
+    WAVE, TILED, CELLS = 1, 2, 3
+    for S in (8, 10, 12, 14, 16):
+        assert plan(S, S, 65536) == (WAVE, 0, 0, 0, 0)
+    assert plan(10, 20, 4096)[0] == WAVE and plan(11, 11, 4096)[0] == CELLS and plan(15, 15, 100)[0] == CELLS
+    assert plan(24, 24, 100)[0] == CELLS and plan(28, 27, 100)[0] == CELLS          # tiled-eligible, but fewer than 784 cells
+    assert plan(30, 30, 100)[0] == CELLS and plan(50, 50, 100)[0] == CELLS          # W % 4 != 0
+    assert plan(64, 260, 100)[0] == CELLS                                             # W > 256
+    # (family, one launch, rows per strip, waves per workgroup, step loop)
+    assert plan(28, 28, 16384) == (TILED, 1, 7, 1, 0)
+    assert plan(32, 32, 16384) == (TILED, 1, 8, 1, 0)            # four strips of 8 rows side by side in one wave
+    assert plan(48, 48, 8192) == (TILED, 1, 12, 1, 0)
+    assert plan(64, 64, 16384) == (TILED, 1, 16, 1, 0)           # a job of many waves: the long strips
+    assert plan(64, 64, 4096) == (TILED, 1, 8, 2, 0)             # fewer than 8 192 waves: twice the waves, half the strip
+    assert plan(64, 64, 2048) == (TILED, 1, 8, 2, 1)             # ... and n-step calls inside one launch
+    assert plan(64, 64, 24) == (TILED, 1, 8, 2, 1)               # never shorter than 8 rows for the sake of more waves
+    assert plan(128, 128, 1024) == (TILED, 1, 8, 8, 0)
+    assert plan(128, 128, 4096) == (TILED, 1, 16, 4, 0)
+    assert plan(128, 128, 512) == (TILED, 1, 8, 8, 1)
+    assert plan(256, 256, 256) == (TILED, 1, 16, 16, 1)          # a small job of 16-wave workgroups
+    assert plan(256, 256, 1024) == (TILED, 0, 0, 0, 0)           # BASELINE configs[3]: the two-launch form
+    assert plan(100, 64, 3000) == (TILED, 1, 13, 2, 1) and plan(300, 64, 1000) == (TILED, 1, 8, 10, 0)
+    assert plan(300, 64, 3000) == (TILED, 0, 0, 0, 0)            # five waves per workgroup and a big job
+    assert plan(600, 256, 10) == (TILED, 0, 0, 0, 0)             # more rows than 16 one-strip waves cover
+    assert lib.wf_step_plan(64, 64, 4096, None, None, None, None) == TILED
+
+
 def test_default_params_match_reference_constants():
     p = N.default_params()
     assert (p.ignite_count, p.allow_dig_toggle, p.containment, p.auto_reset) == (19, 0, 1, 0)

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("wf_step_kernel_name", ctypes.c_char_p, [_vp]),
     ("wf_step_launches", _i, [_vp]),
     ("wf_call_launches", _i, [_vp, _i]),
+    ("wf_step_plan", _i, [_i, _i, _i] + [ctypes.POINTER(_i)] * 4),
     ("wf_call_kernel_name", ctypes.c_char_p, [_vp, _i]),
     ("wf_reload_env", _i, [_vp]),
 ]

@@ -1287,6 +1287,21 @@ int wf_call_launches(const wf_ctx *c, int n_steps)
     return rows_loop ? c->n_parts : per_step * n_steps;
 }
 
+int wf_step_plan(int height, int width, int batch, int *one_launch, int *rows, int *waves, int *step_loop)
+{
+    const WfFamily fam = height > 0 && width > 0 ? wf_pick_family(height, width) : WF_FAM_NONE;
+    int r = 0, w = 0;
+    if (fam == WF_FAM_TILED && batch > 0) {
+        r = wf_tiled_solo_rows(height, width, 0, batch);
+        w = wf_tiled_solo_waves(height, width, r);
+    }
+    if (one_launch) *one_launch = r > 0;
+    if (rows) *rows = r;
+    if (waves) *waves = w;
+    if (step_loop) *step_loop = r > 0 && wf_tiled_solo_fits(height, width, r, true, false) && (long long)batch * w < WF_TILED_SOLO_WAVES;
+    return (int)fam;
+}
+
 #ifdef WF_WAVE_TIMING
 // measurement builds only: device buffer of 5 x u64 per wave of a step launch (see wf_step_rows)
 int wf_debug_timing(wf_ctx *c, void *d_buf) { if (!c) return WF_ERR_ARG; c->dbg_timing = d_buf; return WF_OK; }
