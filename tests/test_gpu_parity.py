@@ -323,11 +323,12 @@ def test_big_grid_step_matches_oracle(wf, monkeypatch, W, H, B):
     _run_big_grid(wf, monkeypatch, W, H, B)
 
 
-@pytest.mark.parametrize("W,H,rows", [(64, 64, 16), (64, 64, 4), (32, 32, 16), (32, 32, 2), (128, 128, 16), (48, 40, 5), (128, 60, 9)])
+@pytest.mark.parametrize("W,H,rows", [(64, 64, 16), (64, 64, 4), (32, 32, 16), (32, 32, 2), (128, 128, 16), (48, 40, 5), (128, 60, 9),
+                                        (32, 32, 1), (256, 16, 1), (12, 80, 0)])
 def test_one_launch_tiled_step_with_any_strip_height(wf, monkeypatch, W, H, rows):
     """The one-launch tiled step takes strips of fewer than 16 rows where that suits the job (wf_tiled_solo_rows: small
     test batches get the short ones); WF_TILED_ROWS picks the height, here the full 16 and odd ones."""
-    monkeypatch.setenv("WF_TILED_ROWS", str(rows))
+    monkeypatch.setenv("WF_TILED_ROWS", str(rows))                # (0: the default, here for a grid three quads wide)
     _run_big_grid(wf, monkeypatch, W, H, 20)
 
 
