@@ -290,6 +290,19 @@ def run_leg(name, S, B, *, noop, ppm=0, env_id0=0, steps, warmup, ticks_per_call
                                 if n > 1 else "8 B per cell-update"}}
     if get_state:
         out["get_state"] = get_state
+    if name.startswith("mid_"):
+        # what a learner that reads World.get_state() after every step pays on the tiled family: the step kernel writes
+        # the observation itself (11 B per cell-update: + 3 B of observation)
+        d_obs = torch.empty((B, S, S, 3), dtype=torch.int8, device=dev)
+        so = Stepper(env, d_act, d_rew, d_done, n_steps=1, mask=1, d_obs=d_obs)
+        so.run(0, 10)
+        env.sync()
+        env.timer_start()
+        so.run(10, 40)
+        ous = env.timer_stop() / 40 * 1e3
+        out["step_plus_observation"] = {"fused_us_per_step": ous, "achieved": 11 * cells / (ous * 1e-6) / 1e9, "unit": "GB/s",
+                                        "frac": 11 * cells / (ous * 1e-6) / 1e9 / HBM_PEAK_GBS, "bytes_per_cell": 11}
+        del d_obs
     env.close()
     del d_act, d_rew, d_done
     torch.cuda.empty_cache()
