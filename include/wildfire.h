@@ -30,7 +30,7 @@
  *             plane 2 heat   number of heat quanta received = temp / (wind_speed*heat)
  *                            (environment.py:286-290); WF_HEAT_FORCED marks
  *                            temp = threshold+1 written by set_fire_to (:236-237)
- *             plane 3 agent  agent_pos layer (utility.py:121)
+ *             plane 3 agent  agent_pos layer (utility.py:121): 0 or 1 (wf_upload refuses other values)
  *   counts  only with wind (wf_params.wind_mode != 0): uint8 (batch, H, W, 4), see wf_wind_counts_upload
  *   envs    wf_env[batch]: agent and world scalars (Agent.x/.y/.dead/.digging,
  *           World.RUNNING/.fire_at_border, "border deque exhausted")

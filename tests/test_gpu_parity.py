@@ -1866,6 +1866,9 @@ def test_api_edge_cases(wf):
     assert lib.wf_upload(env._h, N.ptr(weird), None) == -1
     weird[2, 3, 4, 0] = -1
     assert lib.wf_upload(env._h, N.ptr(weird), N.ptr(ge)) == -1
+    weird[2, 3, 4, 0] = gp[2, 3, 4, 0]
+    weird[4, 7, 7, 3] = 2                                # agent_pos is 0 or 1 (utility.py:121)
+    assert lib.wf_upload(env._h, N.ptr(weird), None) == -1
     gp2, ge2 = env.download()
     np.testing.assert_array_equal(gp2, gp)
     np.testing.assert_array_equal(ge2, ge)

@@ -194,6 +194,7 @@ bool types_ok(const wf_ctx *c, const int8_t *planes)
         for (size_t i = lo; i < hi; ++i) {
             const uint32_t t = (uint8_t)planes[4 * i];
             bad |= (t > 15u ? 1u : 0u) | (((allowed >> (t & 15u)) & 1u) ^ 1u);
+            bad |= (uint8_t)planes[4 * i + 3] > 1u ? 1u : 0u;          // agent_pos is 0 or 1 (utility.py:121; the tiled family's observation tile holds it as a bit)
         }
         return bad;
     };
@@ -852,7 +853,7 @@ int wf_upload(wf_ctx *c, const int8_t *planes, const wf_env *envs)
     if (envs)
         for (int i = 0; i < c->batch; ++i)
             if (envs[i].x >= c->W || envs[i].y >= c->H) return WF_ERR_ARG;
-    // ... and so is a cell type the context's kernels do not know (codes 5 / 6 exist only with allow_dig_toggle, 13 / 6
+    // ... and so is an agent_pos byte other than 0 / 1 or a cell type the context's kernels do not know (codes 5 / 6 exist only with allow_dig_toggle, 13 / 6
     // only with make_rivers, see wildfire.h).  Large uploads are checked by several host threads (the scalar loop cost
     // 0.1 s per upload of the 1 M-environment configuration).
     if (planes && !types_ok(c, planes)) return WF_ERR_ARG;

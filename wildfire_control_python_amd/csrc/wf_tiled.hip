@@ -71,27 +71,28 @@ typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 // fire_mobility != inf) of its 64 rows row-major in LDS - 12 contiguous bytes per lane and row, conflict-free dword
 // writes - and, once its four strips are done, thread x walks down column x: four rows' triples are four unaligned LDS
 // dword reads, packed into the 12 contiguous bytes obs[x][4g..4g+3][0..2].  Needs H % 4 == 0 (4-byte aligned runs).
-struct ObsTile { uint8_t *base; uint32_t W3, row0; };        // LDS tile [rows of the workgroup][pitch W3 = W*3 + 4] (+4 bytes), first row of the workgroup
+// The tile holds THREE BITS per cell - agent_pos, type == fire, fire_mobility != inf; the observation's bytes are 0 or 1
+// (wf_upload refuses agent_pos bytes other than 0 and 1) - i.e. 12 bits per lane and row, a sixth of the byte triples it
+// held until round 4: 128 rows of 128 cells are 8.5 KiB instead of 49, which is what lets a CU hold more than two such
+// workgroups (and a 256x256 grid's tile fit a launch's LDS at all).
+struct ObsTile { uint8_t *base; uint32_t W3, row0; };        // LDS tile [rows of the workgroup][pitch W3 = W/2 + 4 bytes], first row of the workgroup
+#define WF_OBS_PITCH(W) ((W) / 2 + 4)                        // two bytes per quad; + 4: the rows of a column's piece in different banks
 
 __device__ __forceinline__ void stage_obs_row(const ObsTile &ot, uint32_t r, uint32_t lane, const uint32_t (&c)[4])
 {
-    uint32_t tri[4];
+    uint32_t bits = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t t = c[j] & 0xffu;
-        tri[j] = (c[j] >> 24) | (((FIRE_SET >> t) & 1u) << 8) | (t < (uint32_t)WF_DIRT ? 0x10000u : 0u);
+        bits |= (((c[j] >> 24) & 1u) | (((FIRE_SET >> t) & 1u) << 1) | (t < (uint32_t)WF_DIRT ? 4u : 0u)) << (3 * j);
     }
-    uint32_t *p = reinterpret_cast<uint32_t *>(ot.base + (r - ot.row0) * ot.W3 + lane * 12u);
-    p[0] = tri[0] | (tri[1] << 24);
-    p[1] = (tri[1] >> 8) | (tri[2] << 16);
-    p[2] = (tri[2] >> 16) | (tri[3] << 8);
+    *reinterpret_cast<uint16_t *>(ot.base + (r - ot.row0) * ot.W3 + lane * 2u) = (uint16_t)bits;
 }
 
 // rows [row0, row0 + nrows) of the tile -> obs_e (this environment's (W, H, 3) block); nrows % 4 == 0.
 // A column x of the observation is nrows * 3 CONTIGUOUS bytes: consecutive threads take consecutive 12-byte pieces (four
 // rows' triples) of one column, so a wave's store covers a few whole columns instead of 64 pieces of 64 columns
-// (4 096 x 64x64 with the observation: 65 us per step with a thread per column).  The tile's pitch of W * 3 + 4 bytes keeps
-// the pieces of a column - four rows apart - in different LDS banks.
+// (4 096 x 64x64 with the observation: 65 us per step with a thread per column).
 __device__ __forceinline__ void flush_obs_tile(const ObsTile &ot, uint32_t nrows, uint32_t W, uint32_t H, int8_t *obs_e)
 {
     struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -100,14 +101,12 @@ __device__ __forceinline__ void flush_obs_tile(const ObsTile &ot, uint32_t nrows
     const uint32_t sh = 31u - (uint32_t)__builtin_clz(G4 | 1u);
     for (uint32_t i = threadIdx.x; i < items; i += blockDim.x) {
         const uint32_t x = pow2 ? i >> sh : i / G4, g = (i - x * G4) * 4u;
-        // a triple at byte 3x of its row: the two aligned dwords around it, funnel-shifted (an unaligned LDS dword read
-        // takes the LDS several passes: 29 of a 58 us launch were LDS time, profiles/r04_experiments.txt)
-        const uint32_t xb = x * 3u, sh8 = (xb & 3u) * 8u;
+        const uint32_t qoff = (x >> 2) * 2u, bsh = (x & 3u) * 3u;
         uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(ot.base + (g + (uint32_t)k) * ot.W3 + (xb & ~3u));
-            v[k] = __funnelshift_r(p[0], p[1], sh8) & 0xffffffu;
+            const uint32_t b = (uint32_t)*reinterpret_cast<const uint16_t *>(ot.base + (g + (uint32_t)k) * ot.W3 + qoff) >> bsh;
+            v[k] = (b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14);                 // the cell's three bits -> its three bytes
         }
         *reinterpret_cast<U3 *>(obs_e + ((size_t)x * H + ot.row0 + g) * 3u) =
             U3{ v[0] | (v[1] << 24), (v[1] >> 8) | (v[2] << 16), (v[2] >> 16) | (v[3] << 8) };
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
     __shared__ uint4 s_ev;                           // SOLO: the environment's record between big_pre_env and big_post_env
     __shared__ uint32_t s_word[2], s_red[MAXW][2];   // SOLO: step mode, the flood's "changed"; per wave: result bits, healthy cells
     // [SOLO with the containment test: the sweep's collected masks, nw * 16 * COLLECT_WORDS words]
-    // [OBS: [rows of the workgroup][W*3] (+4) staging tile | solo_flood's area, once the tile has been flushed]
+    // [OBS: the observation's staging tile, [rows of the workgroup][W/2 + 4 bytes] | solo_flood's area, once the tile has been flushed]
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     constexpr uint32_t LWP = Pack<P>::LWP;                       // lanes per segment
     const uint32_t WR = (uint32_t)P * tr;                        // rows per wave (tr per strip: TR, fewer for small SOLO grids)
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(SOLO ? WF_SOLO_MAX_WAVES * 64 : 256) void wf_step_t
             md = mode[e];
         }
         const uint32_t wg_row0 = (bid % gx) * nw * WR;
-        const ObsTile ot = { obs_lds, W * 3u + 4u, wg_row0 };
+        const ObsTile ot = { obs_lds, WF_OBS_PITCH(W), wg_row0 };
         int8_t *obs_e = OBS ? a.obs + (size_t)e * H * W * 3u : nullptr;
         if ((md & MODE_MASK) != MODE_STEP) {                   // frozen / freshly reset environment: nothing to step
             const bool fresh = (md & MODE_MASK) == MODE_RESET;  // auto-reset: World.reset() of this environment's cells, here
@@ -803,7 +802,7 @@ static size_t solo_lds(const TiledShape &ts, int H, int W, bool containment, boo
 {
     const size_t collect_lds = containment ? (size_t)ts.nw * TR * COLLECT_WORDS * 8 : 0;
     const size_t flood_lds = containment ? ((size_t)H * (4 / ts.P) + (size_t)H * 4) * 8 : 0;
-    const size_t obs_lds = obs ? (size_t)ts.rows_per_wg * (W * 3 + 4) + 16 : 0;
+    const size_t obs_lds = obs ? (size_t)ts.rows_per_wg * WF_OBS_PITCH(W) + 16 : 0;
     return collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
 }
 int wf_tiled_solo_waves(int H, int W, int rows) { return rows > 0 ? tiled_shape(H, W, rows, WF_SOLO_MAX_WAVES).nw : 0; }
@@ -849,7 +848,7 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
                            (uint32_t)ts.rows_per_wg);
         (void)auto_seed;       // == cold->p.seed: finished environments are reset by the tick kernel itself
         const dim3 grid(gx * (unsigned)a.batch), block(64u * (unsigned)ts.nw);
-        const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * (a.W * 3 + 4) + 16 : 0;      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
+        const size_t obs_lds = a.obs ? (size_t)ts.rows_per_wg * WF_OBS_PITCH(a.W) + 16 : 0;      // fused World.get_state(): the caller checked wf_tiled_fused_obs(H, W)
 #define WF_TILED_LAUNCH(OBS, P) hipLaunchKernelGGL((wf_step_tiled<OBS, P, false>), grid, block, obs_lds, s, a, mode, acc, (const u64 *)halo, (uint32_t)TR)
         if (a.obs) { if (ts.P == 4) WF_TILED_LAUNCH(true, 4); else if (ts.P == 2) WF_TILED_LAUNCH(true, 2); else WF_TILED_LAUNCH(true, 1); }
         else { if (ts.P == 4) WF_TILED_LAUNCH(false, 4); else if (ts.P == 2) WF_TILED_LAUNCH(false, 2); else WF_TILED_LAUNCH(false, 1); }
