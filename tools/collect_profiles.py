@@ -67,8 +67,9 @@ for cfg, kern, what in (("c3", "wf_step_rows", "65 536 x 14x14 (51 MB of state; 
                         ("c2", "wf_step_ticks", "4 096 x 10x10, no-op, 16 ticks per call (1.6 MB; the c2 leg of a bench run under WF_NO_SPLIT=1: ONE launch per call; "
                                                "un-profiled a call is four part launches on the context's streams)"),
                         ("wind", "wf_step_group", "65 536 x 14x14, wind 'random' (51 MB of planes + 51 MB of heat counts; the c3_wind leg of a bench run under WF_NO_SPLIT=1: one launch per step)"),
-                        ("mid", "wf_step_tiled", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch per step - wf_step_tiled<.., SOLO> is the whole step: agent logic, tick, flood, reward)"),
-                        ("mid128", "wf_step_tiled", "1 024 x 128x128 (67 MB; the mid_128 leg of a bench run under WF_NO_SPLIT=1: one launch per step, eight-wave workgroups)")):
+                        ("mid", "wf_step_tiled<false", "4 096 x 64x64 (67 MB; the mid_64 leg of a bench run under WF_NO_SPLIT=1: one launch per step - wf_step_tiled<.., SOLO> is the whole step: agent logic, tick, flood, reward)"),
+                        ("mid128", "wf_step_tiled<false", "1 024 x 128x128 (67 MB; the mid_128 leg of a bench run under WF_NO_SPLIT=1: one launch per step, eight-wave workgroups; "
+                                                   "<false: the step without the observation - the leg's step_plus_observation launches are the <true rows)")):
     lines.append(f"# {cfg}: {what}; separate rocprofv3 --pmc passes; mean over the launches; FETCH_SIZE / WRITE_SIZE in KiB as reported")
     for d in sorted(glob.glob(f"{src}/pmc_{cfg}_*")):
         if not os.path.isdir(d):
