@@ -314,7 +314,8 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               # WF_NO_SOLO=1 keeps the two-launch form covered everywhere (B + 20000)
               (64, 64, 20024), (128, 128, 20006), (64, 100, 20012), (32, 20, 30064), (64, 300, 20006), (100, 140, 20004),
               (256, 256, 20003),
-              (28, 28, 64), (28, 27, 64)]                            # the smallest grids the tiled family takes by itself / not
+              (28, 28, 64), (28, 27, 64),                            # the smallest grids the tiled family takes by itself / not
+              (32, 200, 12), (20, 60, 30), (32, 32, 300), (32, 64, 20040)]   # up to 32 cells wide: eight strips side by side per wave (one launch)
 
 
 @pytest.mark.parametrize("W,H,B", BIG_SHAPES)

@@ -58,8 +58,9 @@ def test_step_plan_of_the_kernel_families():
     assert plan(30, 30, 100)[0] == CELLS and plan(50, 50, 100)[0] == CELLS          # W % 4 != 0
     assert plan(64, 260, 100)[0] == CELLS                                             # W > 256
     # (family, one launch, rows per strip, waves per workgroup, step loop)
-    assert plan(28, 28, 16384) == (TILED, 1, 7, 1, 0)
-    assert plan(32, 32, 16384) == (TILED, 1, 8, 1, 0)            # four strips of 8 rows side by side in one wave
+    assert plan(28, 28, 16384) == (TILED, 1, 4, 1, 0)
+    assert plan(32, 32, 16384) == (TILED, 1, 4, 1, 0)            # eight strips of 4 rows side by side in one wave
+    assert plan(200, 32, 100) == (TILED, 1, 7, 4, 1)             # (height 200, width 32: eight strips of at most 8 rows)
     assert plan(48, 48, 8192) == (TILED, 1, 12, 1, 0)
     assert plan(64, 64, 16384) == (TILED, 1, 16, 1, 0)           # a job of many waves: the long strips
     assert plan(64, 64, 4096) == (TILED, 1, 8, 2, 0)             # fewer than 8 192 waves: twice the waves, half the strip

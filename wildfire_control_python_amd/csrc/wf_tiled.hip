@@ -123,7 +123,7 @@ template <int P>
 struct Pack {
     static constexpr uint32_t LWP = 64u / (uint32_t)P;                   // lanes per segment
     static constexpr u64 SEG0 = P == 1 ? ~0ull : ((1ull << (LWP % 64u)) - 1ull);
-    static constexpr u64 X0 = P == 1 ? 1ull : P == 2 ? 0x0000000100000001ull : 0x0001000100010001ull;   // first lane of every segment
+    static constexpr u64 X0 = P == 1 ? 1ull : P == 2 ? 0x0000000100000001ull : P == 4 ? 0x0001000100010001ull : 0x0101010101010101ull;   // first lane of every segment
     static constexpr u64 XE = X0 << (LWP - 1u);                          // last lane of every segment
     uint32_t tr;             // rows per strip (TR; fewer where that gives a small grid's workgroup more waves: tiled_shape)
     uint32_t row_off;        // this lane's segment * tr: its row at sweep position r is r + row_off
@@ -273,7 +273,7 @@ __device__ __forceinline__ void tiled_sweep(uint32_t r0, uint32_t r1, uint32_t H
 template <int P>
 __device__ __forceinline__ uint32_t solo_flood(const WfArgs &a, const uint32_t e, const uint32_t tr, const u64 *collect, u64 *area, uint32_t *changed)
 {
-    constexpr int NW = 4 / P;                                    // words of a linear row bitmap: W <= 64 * NW
+    constexpr int NW = P >= 4 ? 1 : 4 / P;                       // words of a linear row bitmap: W <= 64 * NW
     constexpr uint32_t LWP = Pack<P>::LWP;
     const uint32_t WR = (uint32_t)P * tr;
     const uint32_t H = (uint32_t)a.H, W = (uint32_t)a.W, t = threadIdx.x, nt = blockDim.x;
@@ -761,7 +761,10 @@ static TiledShape tiled_shape(int H, int W, int tr = TR, int max_waves = 4)
 {
     TiledShape t;
     const int LW = W / 4;
-    t.P = LW <= 16 ? 4 : LW <= 32 ? 2 : 1;
+    // (eight strips side by side for grids up to 32 cells wide - every lane of a 32x32 grid's wave busy instead of half of
+    // them - in the one-launch form only, with strips of at most 8 rows: a wave's river table holds 64 rows)
+    t.P = LW <= 8 && max_waves > 4 ? 8 : LW <= 16 ? 4 : LW <= 32 ? 2 : 1;
+    if (t.P == 8 && tr > 8) tr = 8;
     t.tr = tr;
     const int rows_per_wave = t.P * tr;
     t.nw = (H + rows_per_wave - 1) / rows_per_wave;
@@ -801,7 +804,7 @@ int wf_tiled_solo_rows(int H, int W, int want, int batch)
 static size_t solo_lds(const TiledShape &ts, int H, int W, bool containment, bool obs)
 {
     const size_t collect_lds = containment ? (size_t)ts.nw * TR * COLLECT_WORDS * 8 : 0;
-    const size_t flood_lds = containment ? ((size_t)H * (4 / ts.P) + (size_t)H * 4) * 8 : 0;
+    const size_t flood_lds = containment ? ((size_t)H * (ts.P >= 4 ? 1 : 4 / ts.P) + (size_t)H * 4) * 8 : 0;
     const size_t obs_lds = obs ? (size_t)ts.rows_per_wg * WF_OBS_PITCH(W) + 16 : 0;
     return collect_lds + (obs_lds > flood_lds ? obs_lds : flood_lds);
 }
@@ -829,10 +832,10 @@ hipError_t wf_launch_step_big(WfFamily fam, const WfArgs &a, uint8_t *mode, uint
 #define WF_SOLO_LOOP(P) hipLaunchKernelGGL((wf_step_tiled<false, P, true, true>), grid, block, lds, s, a, (const uint8_t *)nullptr, (uint32_t *)nullptr, (const u64 *)nullptr, (uint32_t)ts.tr)
         if (a.n_steps > 1) {        // the step loop (the caller keeps the observation's step out of it)
             if (a.obs) return hipErrorInvalidValue;
-            if (ts.P == 4) WF_SOLO_LOOP(4); else if (ts.P == 2) WF_SOLO_LOOP(2); else WF_SOLO_LOOP(1);
+            if (ts.P == 8) WF_SOLO_LOOP(8); else if (ts.P == 4) WF_SOLO_LOOP(4); else if (ts.P == 2) WF_SOLO_LOOP(2); else WF_SOLO_LOOP(1);
         } else
-        if (a.obs) { if (ts.P == 4) WF_SOLO_LAUNCH(true, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(true, 2); else WF_SOLO_LAUNCH(true, 1); }
-        else { if (ts.P == 4) WF_SOLO_LAUNCH(false, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(false, 2); else WF_SOLO_LAUNCH(false, 1); }
+        if (a.obs) { if (ts.P == 8) WF_SOLO_LAUNCH(true, 8); else if (ts.P == 4) WF_SOLO_LAUNCH(true, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(true, 2); else WF_SOLO_LAUNCH(true, 1); }
+        else { if (ts.P == 8) WF_SOLO_LAUNCH(false, 8); else if (ts.P == 4) WF_SOLO_LAUNCH(false, 4); else if (ts.P == 2) WF_SOLO_LAUNCH(false, 2); else WF_SOLO_LAUNCH(false, 1); }
 #undef WF_SOLO_LAUNCH
 #undef WF_SOLO_LOOP
         return hipGetLastError();
