@@ -314,7 +314,7 @@ BIG_SHAPES = [(24, 24, 96), (32, 20, 64), (64, 64, 24), (100, 37, 16), (256, 70,
               # WF_NO_SOLO=1 keeps the two-launch form covered everywhere (B + 20000)
               (64, 64, 20024), (128, 128, 20006), (64, 100, 20012), (32, 20, 30064), (64, 300, 20006), (100, 140, 20004),
               (256, 256, 20003),
-              (28, 28, 64), (28, 27, 64),                            # the smallest grids the tiled family takes by itself / not
+              (28, 28, 64), (28, 27, 64), (24, 23, 64),              # around the smallest grid the tiled family takes by itself (24x24, above)
               (32, 200, 12), (20, 60, 30), (32, 32, 300), (32, 64, 20040)]   # up to 32 cells wide: eight strips side by side per wave (one launch)
 
 
@@ -430,7 +430,7 @@ def _run_big_grid(wf, monkeypatch, W, H, B):
     env = wf.BatchedForestFire(B, width=W, height=H, seed=5, fuel_range=(3, 12), ignite_ppm=15000,
                                auto_reset=auto)
     assert "tiled" in env.kernel_name or "cells" in env.kernel_name
-    assert ("tiled" in env.kernel_name) == (W % 4 == 0 and W <= 256 and (W * H > 783 or forced_tiled))
+    assert ("tiled" in env.kernel_name) == (W % 4 == 0 and W <= 256 and (W * H > 575 or forced_tiled))
     if "cells" in env.kernel_name:
         legacy = "WF_CELLS_LEGACY" in __import__("os").environ or (W * H > 1024 and B < 512)
         assert env.step_kernel == ("wf_step_cells" if legacy else "wf_step_env")

@@ -54,7 +54,8 @@ def test_step_plan_of_the_kernel_families():
     for S in (8, 10, 12, 14, 16):
         assert plan(S, S, 65536) == (WAVE, 0, 0, 0, 0)
     assert plan(10, 20, 4096)[0] == WAVE and plan(11, 11, 4096)[0] == CELLS and plan(15, 15, 100)[0] == CELLS
-    assert plan(24, 24, 100)[0] == CELLS and plan(28, 27, 100)[0] == CELLS          # tiled-eligible, but fewer than 784 cells
+    assert plan(20, 20, 100)[0] == CELLS and plan(23, 24, 100)[0] == CELLS          # tiled-eligible, but fewer than 576 cells
+    assert plan(24, 24, 32768) == (TILED, 1, 3, 1, 0)            # the smallest: eight strips of 3 rows
     assert plan(30, 30, 100)[0] == CELLS and plan(50, 50, 100)[0] == CELLS          # W % 4 != 0
     assert plan(64, 260, 100)[0] == CELLS                                             # W > 256
     # (family, one launch, rows per strip, waves per workgroup, step loop)

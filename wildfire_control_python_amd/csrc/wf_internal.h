@@ -101,7 +101,7 @@ enum WfFamily { WF_FAM_NONE = 0, WF_FAM_WAVE = 1, WF_FAM_TILED = 2, WF_FAM_CELLS
 // Returns the family able to serve (H, W), and its name.
 WfFamily wf_pick_family(int H, int W);
 bool wf_tiled_serves(int H, int W);        // the tiled family can run this shape (WF_FAMILY=tiled forces it below its size threshold)
-#define WF_TILED_MIN_CELLS 783             // below 28x28 the generic family is the faster one (wf_pick_family)
+#define WF_TILED_MIN_CELLS 575             // below 24x24 the generic family is the faster one (wf_pick_family)
 const char *wf_family_name(WfFamily f, int H, int W);
 
 // Single-step group kernel: environments per wave, sized so that every resident wave slot of

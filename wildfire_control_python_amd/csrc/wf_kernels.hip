@@ -623,9 +623,9 @@ WfFamily wf_pick_family(int H, int W)
     WF_WAVE_SHAPES(X)
 #undef X
     // a wave of the tiled family has a fixed part worth about five rows of sweep, and narrow grids leave lanes idle:
-    // below 28x28 the generic family's wave-per-environment kernel is faster (us per step, generic against the tiled
-    // family's one-launch step, round 4: 32 768 x 20x20 49 against 60, 32 768 x 24x24 61 against 66, 16 384 x 28x28 44
-    // against 37, 16 384 x 32x32 - against 39, 8 192 x 48x48 - against 30)
+    // below 24x24 the generic family's wave-per-environment kernel is faster or as fast (us per step, generic against
+    // the tiled family's one-launch step with eight strips per wave, round 4: 32 768 x 20x20 49 against 53 - 4 096: 19
+    // against 15 -, 32 768 x 24x24 61 against 54 - 4 096: 21 against 15 -, 16 384 x 28x28 44 against 30)
     if (W >= 4 && W <= 256 && W % 4 == 0 && H >= 1 && (long long)H * W > WF_TILED_MIN_CELLS) return WF_FAM_TILED;
     return WF_FAM_CELLS;
 }

@@ -2,7 +2,7 @@
 //
 // Same rule as wf_kernels.hip (synchronous integer restatement of
 // Simulation/forest_fire.py:85-106 + Simulation/environment.py:278-326).  One step of the TILED family
-// (W % 4 == 0, W <= 256, at least 784 cells) is ONE launch of wf_step_tiled<.., SOLO> - a workgroup per environment
+// (W % 4 == 0, W <= 256, at least 576 cells) is ONE launch of wf_step_tiled<.., SOLO> - a workgroup per environment
 // does what the two kernels below do between them, see there - or, for jobs of thousands of waves in workgroups
 // of more than four (1 024 x 256x256) and for observation tiles past a launch's LDS, two launches:
 //   wf_tiled_prologue   one workgroup per environment: Agent.move / toggle / death (environment.py:116-171) with
