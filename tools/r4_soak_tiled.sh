@@ -7,6 +7,8 @@ dev t64 250 4096 64 5 25
 dev t128 250 1024 128 7 25
 dev t32 250 16384 32 9 25
 dev t48 250 6000 48 3 25
+dev t28 250 12000 28 19 25
+dev t24 250 16000 24 23 25
 dev t256_small 120 200 256 11 20
 dev t100 200 1500 100 13 25
 WF_TILED_ROWS=16 dev t64_rows16 150 4096 64 15 25
@@ -17,6 +19,7 @@ STEPS=480 SEED=21
 BATCH=1024 SIZE=64 run loop64 STEPS_PER_CALL=16
 BATCH=300 SIZE=128 run loop128 STEPS_PER_CALL=8
 BATCH=3000 SIZE=32 run loop32 STEPS_PER_CALL=60
+BATCH=4000 SIZE=24 run loop24_rare OPTIONS=rivers,toggle STEPS_PER_CALL=9
 BATCH=1500 SIZE=48 run loop48_rare OPTIONS=rivers,toggle STEPS_PER_CALL=12
 BATCH=100 SIZE=256 run loop256 STEPS_PER_CALL=5
 BATCH=2500 SIZE=64 run loop64_parts STEPS_PER_CALL=16
